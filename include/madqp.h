@@ -1,0 +1,232 @@
+/*
+ * madqp.h -- C ABI of libmadqp_hip.so: the MI355X (gfx950) implementation of the
+ * Mehrotra predictor-corrector KKT hot path of MadIPM / MadQP.jl.
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes
+ * plain pointers and sizes, returns an int32 status and never throws or aborts:
+ *     0  MADQP_OK
+ *    <0  usage / runtime error (text via madqp_last_error)
+ *    >0  numerical condition (not positive definite at column j, NaN detected)
+ *
+ * Conventions
+ *   - all `double*` / `int64_t*` arguments are DEVICE pointers unless the name ends in
+ *     `_host`; scalar results are returned through host pointers (the call synchronises
+ *     the context's stream when it returns a scalar; calls that return nothing are
+ *     asynchronous and stream ordered).
+ *   - symmetric matrices / Cholesky factors: column-major, lower triangle, LAPACK 'L'
+ *     (element (i,j), i>=j, at  ptr[i + j*ld]) -- byte-identical to a Julia `Matrix` handed
+ *     to `LAPACK.potrf!('L', ...)`.
+ *   - the constraint matrix A (m x nx) is given with ROW k contiguous:  A[k*lda + i]
+ *     (a numpy C-order array; from Julia pass `permutedims(A)`), because the MFMA kernels
+ *     stage k-major tiles whose fast index is the variable index.
+ *   - index vectors are 0-based int64 (MadNLP's are 1-based Int: the Julia glue passes
+ *     `ind .- 1`).
+ *   - one context = one device + one HIP stream; calls on a context are stream ordered and
+ *     must come from one host thread at a time (the reference loop is single threaded,
+ *     src/solver.jl:254-345).
+ *
+ * Each function names the reference interface (file:line under /root/reference) it replaces.
+ */
+#ifndef MADQP_H
+#define MADQP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MADQP_OK 0
+#define MADQP_ERR_ARG (-1)
+#define MADQP_ERR_HIP (-2)
+#define MADQP_ERR_ALLOC (-3)
+#define MADQP_ERR_STATE (-4)
+#define MADQP_NUM_NAN 1000000001 /* NaN detected (src/linear_solver.jl:41-43) */
+
+typedef struct madqp_ctx madqp_ctx;
+typedef struct madqp_chol madqp_chol;
+typedef struct madqp_kkt madqp_kkt;
+
+/* ------------------------------------------------------------------ context */
+int32_t madqp_version(void);
+/* stream: a hipStream_t to launch on (NULL = the device's default stream). */
+int32_t madqp_ctx_create(int32_t device, void* stream, madqp_ctx** out);
+int32_t madqp_ctx_destroy(madqp_ctx* ctx);
+const char* madqp_last_error(madqp_ctx* ctx);
+int32_t madqp_ctx_sync(madqp_ctx* ctx);
+/* device memory helpers for hosts without their own allocator (Julia glue, C++) */
+int32_t madqp_malloc(madqp_ctx* ctx, size_t bytes, void** out);
+int32_t madqp_free(madqp_ctx* ctx, void* ptr);
+int32_t madqp_memcpy_h2d(madqp_ctx* ctx, void* dst, const void* src_host, size_t bytes);
+int32_t madqp_memcpy_d2h(madqp_ctx* ctx, void* dst_host, const void* src, size_t bytes);
+
+/* Per-kernel-class device timers (hipEvent pairs on the context's stream). */
+enum {
+    MADQP_PROF_SYRK = 0,      /* gemm core, assembly instance            */
+    MADQP_PROF_POTRF_GEMM,    /* gemm core, left-looking panel updates   */
+    MADQP_PROF_POTRF_DIAG,    /* 128x128 diagonal block factor + inverse */
+    MADQP_PROF_POTRF_TRSM,    /* gemm core, panel times inverse block    */
+    MADQP_PROF_TRSV,          /* triangular sweeps of the solves         */
+    MADQP_PROF_GEMV,
+    MADQP_PROF_VEC,           /* fused vector / reduction kernels        */
+    MADQP_PROF_COUNT
+};
+int32_t madqp_prof_enable(madqp_ctx* ctx, int32_t on);
+int32_t madqp_prof_reset(madqp_ctx* ctx);
+/* total device milliseconds and launch count of a class since the last reset (syncs) */
+int32_t madqp_prof_get(madqp_ctx* ctx, int32_t cls, double* ms_host, int64_t* launches_host);
+
+/* ------------------------------------------------------------ synthetic data */
+/* out[i] = g(key, idx0 + i): the position-addressable generator of oracle/qp.py */
+int32_t madqp_gen_normal(madqp_ctx* ctx, uint64_t key, uint64_t idx0, int64_t count, double* out);
+/* dense symmetric "wigner" H (full storage): oracle/qp.py:gen_H_wigner */
+int32_t madqp_gen_wigner(madqp_ctx* ctx, uint64_t key, int64_t n, double inv_sqrt_n, double* H,
+                         int64_t ld);
+
+/* ------------------------------------------------------- dense linear algebra */
+/* C(lower) = base(lower, may be NULL) + diag(dvec, may be NULL) + B' diag(w) B
+ * B: kdim rows of length n (row k at B + k*ldb); w may be NULL (= ones).
+ * Replaces assemble_normal_system! (src/utils.jl:266-298) / build_kkt! (src/KKT/normalkkt.jl:166-180)
+ * for dense data: the SYRK of SURVEY.md 8a-2.  MFMA v_mfma_f64_16x16x4_f64. */
+int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B, int64_t ldb,
+                            const double* w, const double* base, int64_t ldbase,
+                            const double* dvec, double* C, int64_t ldc);
+
+/* Cholesky linear solver: replaces MadNLP.LapackCPUSolver / the AbstractLinearSolver
+ * contract used at src/KKT/normalkkt.jl:99-101,196 and src/linear_solver.jl:10-11. */
+int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out);
+int32_t madqp_chol_destroy(madqp_chol* s);
+/* MadNLP.factorize!: in-place lower Cholesky of the n x n matrix at A (blocked left-looking,
+ * MFMA panel updates).  info_host: 0 = success, j>0 = leading minor of order j not positive
+ * definite (LAPACK dpotrf convention; maps to is_factorized, src/utils.jl:54-62). */
+int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int32_t* info_host);
+/* MadNLP.solve!(linear_solver, rhs): rhs <- (L L')^-1 rhs in place (two triangular sweeps) */
+int32_t madqp_chol_solve(madqp_chol* s, double* rhs);
+
+/* y = alpha*op(A) x + beta*y ; A has `rows` rows of length `cols`, row r at A + r*lda.
+ * trans=0: y(rows) = A x(cols);  trans=1: y(cols) = A' x(rows).
+ * Replaces mul!(y, kkt.AT, x) / mul!(y, kkt.AT', x) (src/KKT/normalkkt.jl:162-164,194,200,214-215). */
+int32_t madqp_gemv(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t cols, double alpha,
+                   const double* A, int64_t lda, const double* x, double beta, double* y);
+
+/* ----------------------------------------------------------- solver state view */
+/* Device-pointer view of MPCSolver (src/structure.jl:1-75) + the diagonal fields of the
+ * KKT system that MadIPM reads generically (src/kernels.jl:135-144).  d and p are
+ * UnreducedKKTVector.values: [x(n) | y(m) | zl(nlb) | zu(nub)] contiguous. */
+typedef struct madqp_state {
+    int64_t n, m, nlb, nub;
+    const int64_t* ind_lb; /* nlb, 0-based, strictly increasing */
+    const int64_t* ind_ub; /* nub */
+    double *x, *xl, *xu, *zl, *zu, *f; /* n */
+    double *y, *c;                     /* m */
+    double* jacl;                      /* n */
+    double *d, *p;                     /* n+m+nlb+nub */
+    double *correction_lb, *correction_ub;
+    double *reg, *pr_diag; /* n */
+    double* du_diag;       /* m */
+    double *l_diag, *l_lower; /* nlb */
+    double *u_diag, *u_lower; /* nub */
+} madqp_state;
+
+/* ---------------------------------------------- src/kernels.jl, fused on device */
+/* set_aug_diagonal_reg! (src/kernels.jl:128-146) */
+int32_t madqp_set_aug_diagonal_reg(madqp_ctx* ctx, const madqp_state* st, double del_w,
+                                   double del_c);
+/* set_initial_primal_rhs! / set_initial_dual_rhs! (src/kernels.jl:1-19) */
+int32_t madqp_set_initial_primal_rhs(madqp_ctx* ctx, const madqp_state* st);
+int32_t madqp_set_initial_dual_rhs(madqp_ctx* ctx, const madqp_state* st);
+/* set_predictive_rhs! (src/kernels.jl:21-41) */
+int32_t madqp_set_predictive_rhs(madqp_ctx* ctx, const madqp_state* st);
+/* set_correction_rhs! (src/kernels.jl:43-61) */
+int32_t madqp_set_correction_rhs(madqp_ctx* ctx, const madqp_state* st, double mu);
+/* get_correction! (src/kernels.jl:63-75) */
+int32_t madqp_get_correction(madqp_ctx* ctx, const madqp_state* st);
+/* set_extra_correction! (src/kernels.jl:78-126) */
+int32_t madqp_set_extra_correction(madqp_ctx* ctx, const madqp_state* st, double alpha_p,
+                                   double alpha_d, double beta_min, double beta_max, double mu);
+/* get_complementarity_measure (src/kernels.jl:171-190) */
+int32_t madqp_get_complementarity_measure(madqp_ctx* ctx, const madqp_state* st, double* mu_host);
+/* get_affine_complementarity_measure (src/kernels.jl:192-224) */
+int32_t madqp_get_affine_complementarity_measure(madqp_ctx* ctx, const madqp_state* st,
+                                                 double alpha_p, double alpha_d,
+                                                 double* mu_host);
+/* get_alpha_max_primal + get_alpha_max_dual (src/kernels.jl:242-288) in one launch.
+ * alpha_host[4] = (alpha_xl, alpha_xu, alpha_zl, alpha_zu); iblock_host[4] = 0-based blocking
+ * index into the lb/ub lists, -1 when nothing blocks (the reference's init (1.0, 0)).
+ * Ties resolve to the smallest index (first minimum under the reference's strict '<'). */
+int32_t madqp_get_alpha_max(madqp_ctx* ctx, const madqp_state* st, double tau,
+                            double* alpha_host, int64_t* iblock_host);
+/* axpy! x4 of src/solver.jl:332-335 */
+int32_t madqp_update_iterates(madqp_ctx* ctx, const madqp_state* st, double alpha_p,
+                              double alpha_d);
+/* MadNLP.get_inf_pr / get_inf_du / get_inf_compl as called at src/solver.jl:264-272,
+ * src/kernels.jl:435-446: out_host[3] = (||c||inf, ||f - zl + zu + jacl||inf, max compl product) */
+int32_t madqp_get_inf(madqp_ctx* ctx, const madqp_state* st, double* out_host);
+/* MadNLP.adjust_boundary! (src/solver.jl:342) */
+int32_t madqp_adjust_boundary(madqp_ctx* ctx, const madqp_state* st, double mu);
+/* MadNLP.reduce_rhs! / finish_aug_solve! / _kktmul! on an UnreducedKKTVector
+ * (src/KKT/normalkkt.jl:183,203,217) */
+int32_t madqp_reduce_rhs(madqp_ctx* ctx, const madqp_state* st, double* w);
+int32_t madqp_finish_aug_solve(madqp_ctx* ctx, const madqp_state* st, double* w);
+int32_t madqp_kktmul(madqp_ctx* ctx, const madqp_state* st, double* w, const double* v,
+                     double alpha, double beta);
+/* the three inf-norms of solve_system! (src/linear_solver.jl:29-35):
+ * out_host[3] = (||a||inf, ||b||inf, ||c||inf) over `len` entries each; NaN propagates. */
+int32_t madqp_norm_inf3(madqp_ctx* ctx, int64_t len, const double* a, const double* b,
+                        const double* c, double* out_host);
+int32_t madqp_norm_inf(madqp_ctx* ctx, int64_t len, const double* a, double* out_host);
+int32_t madqp_axpy(madqp_ctx* ctx, int64_t len, double alpha, const double* x, double* y);
+int32_t madqp_copy(madqp_ctx* ctx, int64_t len, const double* src, double* dst);
+int32_t madqp_fill(madqp_ctx* ctx, int64_t len, double value, double* dst);
+
+/* ---------------------------------- init_starting_point! (src/solver.jl:6-125) */
+/* multipliers from res = A'y + f by bound type (src/solver.jl:41-66); res is st->jacl */
+int32_t madqp_sp_init_duals(madqp_ctx* ctx, const madqp_state* st);
+/* out_host[4] = min(0, min(x_lr-xl_r)), min(0, min(xu_r-x_ur)), min(0, min zl_r), min(0, min zu_r)
+ * (src/solver.jl:68-78) */
+int32_t madqp_sp_mins(madqp_ctx* ctx, const madqp_state* st, double* out_host);
+/* x_lr += dx; then x_ur -= dx; zl_r += dz; zu_r += dz (src/solver.jl:80-83, 96-99);
+ * the two primal passes are ordered so the aliasing of x_lr / x_ur is reproduced */
+int32_t madqp_sp_shift(madqp_ctx* ctx, const madqp_state* st, double dx, double dz);
+/* out_host[8] = dot(x_lr,zl_r), dot(xl_r,zl_r), dot(xu_r,zu_r), dot(x_ur,zu_r),
+ *               sum(zl_r), sum(zu_r), sum(x_lr-xl_r), sum(xu_r-x_ur)   (src/solver.jl:85-94) */
+int32_t madqp_sp_sums(madqp_ctx* ctx, const madqp_state* st, double* out_host);
+/* Ipopt-style projection (src/solver.jl:101-118) */
+int32_t madqp_sp_project(madqp_ctx* ctx, const madqp_state* st, double kappa);
+/* the four asserts (src/solver.jl:120-123): ok_host = 1 when all hold */
+int32_t madqp_sp_check(madqp_ctx* ctx, const madqp_state* st, int32_t* ok_host);
+
+/* ------------------------------------------------- condensed dense KKT system */
+/* HIPCondensedKKTSystem: K = H + Sigma_x + A' Theta A  (SURVEY.md 8a-note), modelled on
+ * NormalKKTSystem (src/KKT/normalkkt.jl:1-27).  H (nx x nx, full symmetric storage, may be
+ * NULL for an LP) and A (m x nx, row k contiguous) are BORROWED device pointers that must
+ * outlive the object; K, its factor and all work vectors are owned by the library.
+ * ind_ineq_host: ns 0-based rows that carry a slack (host pointer, copied). */
+int32_t madqp_kkt_create(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
+                         const int64_t* ind_ineq_host, const double* H, int64_t ldh,
+                         const double* A, int64_t lda, madqp_kkt** out);
+int32_t madqp_kkt_destroy(madqp_kkt* kkt);
+/* MadNLP.build_kkt! (src/KKT/normalkkt.jl:166-180): Theta from pr_diag/du_diag, then the SYRK */
+int32_t madqp_kkt_build(madqp_kkt* kkt, const madqp_state* st);
+/* MadNLP.factorize!(kkt.linear_solver); info as madqp_chol_factor */
+int32_t madqp_kkt_factorize(madqp_kkt* kkt, int32_t* info_host);
+/* MadNLP.solve!(kkt, w) (src/KKT/normalkkt.jl:182-205): reduce, condense, two triangular
+ * sweeps, decondense, finish; w is an UnreducedKKTVector.values, solved in place */
+int32_t madqp_kkt_solve(madqp_kkt* kkt, const madqp_state* st, double* w);
+/* MadNLP.mul!(w, kkt, v, alpha, beta) (src/KKT/normalkkt.jl:207-219), with H for a QP */
+int32_t madqp_kkt_mul(madqp_kkt* kkt, const madqp_state* st, double* w, const double* v,
+                      double alpha, double beta);
+/* MadNLP.jtprod!(out, kkt, y) (src/KKT/normalkkt.jl:162-164): out(n) = [A' y ; -y[ind_ineq]] */
+int32_t madqp_kkt_jtprod(madqp_kkt* kkt, double* out, const double* y);
+/* model callbacks of the loop (src/solver.jl:166-169,338-340; formulas scripts/qp_gpu.jl:29-40):
+ * f = [H x + q ; 0], c = A x - s - rhs, obj_host = c0 + q'x + x'Hx/2 (scaled data) */
+int32_t madqp_kkt_eval(madqp_kkt* kkt, const madqp_state* st, const double* q, const double* rhs,
+                       double c0, double* obj_host);
+/* device pointer to the assembled / factored K (nx x nx, ld = madqp_kkt_ld) for inspection */
+int32_t madqp_kkt_matrix(madqp_kkt* kkt, double** K, int64_t* ld);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MADQP_H */

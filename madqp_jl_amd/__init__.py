@@ -1,0 +1,24 @@
+"""madqp_jl_amd -- MI355X-native Mehrotra predictor-corrector KKT path (MadIPM / MadQP.jl).
+
+Hand-written HIP for gfx950 behind a C ABI (``include/madqp.h``, built into
+``libmadqp_hip.so`` from ``csrc/``) plus the host-side mirror of the reference's
+plugin interface: :class:`HIPCondensedKKTSystem` / :class:`HIPCholeskySolver`
+(``MadNLP.AbstractKKTSystem`` / ``AbstractLinearSolver``) and :class:`MPCSolver`
+(the ``mpc!`` loop of ``src/solver.jl``).  There is no CPU fallback.
+"""
+from ._lib import EXPORTED_SYMBOLS, LIB_PATH, MadQPError, load_cdll
+from .backend import HipBackend, State
+from .kkt import HIPCholeskySolver, HIPCondensedKKTSystem
+from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, FixedRegularization,
+                      IPMOptions, MehrotraAdaptiveStep, NoRegularization)
+from .qp import DeviceQP, stream_key
+from .solver import (ERROR_IN_STEP_COMPUTATION, MAXIMUM_ITERATIONS_EXCEEDED, SOLVE_SUCCEEDED,
+                     MPCSolver, SolveException)
+
+__all__ = [
+    "HipBackend", "State", "HIPCholeskySolver", "HIPCondensedKKTSystem", "MPCSolver", "DeviceQP",
+    "IPMOptions", "AdaptiveStep", "ConservativeStep", "MehrotraAdaptiveStep", "NoRegularization",
+    "FixedRegularization", "AdaptiveRegularization", "MadQPError", "SolveException", "load_cdll",
+    "EXPORTED_SYMBOLS", "LIB_PATH", "stream_key", "SOLVE_SUCCEEDED", "MAXIMUM_ITERATIONS_EXCEEDED",
+    "ERROR_IN_STEP_COMPUTATION",
+]

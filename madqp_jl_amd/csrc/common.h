@@ -1,0 +1,118 @@
+// Internal helpers shared by the translation units of libmadqp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/madqp.h"
+
+#define MADQP_RESULT_SLOTS 64
+
+struct ProfEvent {
+    hipEvent_t a, b;
+    int cls;
+};
+
+struct madqp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    // scalar results: device block + pinned host mirror
+    double* d_res = nullptr;
+    double* h_res = nullptr;
+    // reduction partials (MADQP_MAX_BLOCKS x MADQP_RESULT_SLOTS doubles)
+    double* d_part = nullptr;
+    // generic workspace for deterministic two-pass gemv
+    double* d_work = nullptr;
+    size_t work_bytes = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfEvent> pending;
+    std::vector<hipEvent_t> pool;
+    double prof_ms[MADQP_PROF_COUNT] = {0};
+    int64_t prof_n[MADQP_PROF_COUNT] = {0};
+};
+
+static inline int32_t madqp_fail(madqp_ctx* ctx, int32_t code, const char* fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return madqp_fail((ctx), MADQP_ERR_HIP, "%s failed: %s (%s:%d)", #expr,          \
+                              hipGetErrorString(e_), __FILE__, __LINE__);                    \
+    } while (0)
+
+#define ARG_TRY(ctx, cond)                                                                   \
+    do {                                                                                     \
+        if (!(cond))                                                                         \
+            return madqp_fail((ctx), MADQP_ERR_ARG, "bad argument: %s (%s:%d)", #cond,       \
+                              __FILE__, __LINE__);                                           \
+    } while (0)
+
+#define LAUNCH_CHECK(ctx) HIP_TRY(ctx, hipGetLastError())
+
+// ctx.hip
+int32_t madqp_work_reserve(madqp_ctx* ctx, size_t bytes);
+void madqp_prof_begin(madqp_ctx* ctx, int cls);
+void madqp_prof_end(madqp_ctx* ctx);
+int32_t madqp_read_results(madqp_ctx* ctx, int count, double* out_host);
+
+struct ProfScope {
+    madqp_ctx* c;
+    ProfScope(madqp_ctx* ctx, int cls) : c(ctx) {
+        if (c->prof) madqp_prof_begin(c, cls);
+    }
+    ~ProfScope() {
+        if (c->prof) madqp_prof_end(c);
+    }
+};
+
+// gemm_f64.hip
+struct GemmArgs {
+    const double* X;  // X[i + k*ldx], i in [0,M)
+    int64_t ldx;
+    const double* Y;  // Y[j + k*ldy], j in [0,N)
+    int64_t ldy;
+    const double* s;  // optional per-k scale of Y (NULL = 1)
+    double* C;        // out C[i + j*ldc]
+    int64_t ldc;
+    const double* Cin;  // optional addend, same indexing with ldcin (may alias C)
+    int64_t ldcin;
+    const double* dvec;  // optional: added where (i + diag_off == j), indexed by j
+    double alpha, beta;  // out = alpha*acc + beta*Cin (+ dvec)
+    int64_t M, N, K;
+    int64_t diag_off;  // global_row(i) - global_col(j) = i - j + diag_off
+    int lower_only;    // 1: write only elements with i + diag_off >= j; skip tiles above
+};
+int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls);
+
+void madqp_gemm_release_tables(madqp_ctx* ctx);
+
+// gemv.hip (internal entry with explicit class)
+int32_t madqp_gemv_impl(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t cols, double alpha,
+                        const double* A, int64_t lda, const double* x, double beta, double* y,
+                        int prof_cls);
+
+struct madqp_chol {
+    madqp_ctx* ctx;
+    int64_t n;
+    double* winv;  // ceil(n/128) blocks of 128x128 (col-major, ld 128): inverse diagonal blocks
+    double* tmp;   // n doubles
+    int32_t* d_info;
+    double* A;  // last factored matrix (borrowed)
+    int64_t lda;
+    bool factored;
+};

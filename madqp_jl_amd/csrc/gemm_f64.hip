@@ -1,0 +1,288 @@
+// fp64 MFMA GEMM core for gfx950:  C[i,j] = alpha * sum_k X[i,k] s[k] Y[j,k] + beta * Cin[i,j] (+ dvec on the diagonal)
+//
+// One kernel serves the three dense contractions of the hot path:
+//   * condensed-KKT assembly  K = H + Sigma_x + A' Theta A          (madqp_syrk_assemble)
+//   * left-looking Cholesky panel update  C -= L[:, :k] L[J, :k]'   (chol.hip)
+//   * panel times inverse diagonal block  L[:, J] = C[:, J] W'      (chol.hip)
+//
+// Both operands are "k-major": for a fixed k the M (resp. N) entries are contiguous in memory.
+// That is the natural layout of column-major L (column k contiguous) and of row-major A
+// (row k contiguous), so every tile row is one coalesced 1 KiB wave load and both LDS images
+// are [k][index] with the index fastest.
+//
+// Tiling: 128 x 128 output tile per 256-thread workgroup (4 waves = 2 x 2, one per SIMD), each wave
+// owns 64 x 64 = 4 x 4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  K is consumed in
+// stages of 16: global -> registers (prefetch of stage s+1 in flight while stage s computes)
+// -> LDS (double buffered, one barrier per stage).  Per stage a wave issues 64 MFMAs and only
+// 32 ds_read_b64, so the matrix pipe is the only busy resource.  LDS row stride 144 doubles
+// (= 16 mod 32) makes the two k-rows of a 32-lane ds_read_b64 group hit disjoint banks.
+//
+// MFMA operand roles (v_mfma_f64_16x16x4_f64: D[r][c] = sum_k A[r][k] B[k][c]; lane l feeds
+// A[l&15][l>>4] and B[l>>4][l&15]; lane l holds D[(l>>4) + 4v][l&15], v = 0..3):
+//   A-operand <- Y fragment (r = column index j of C),  B-operand <- X fragment (c = row index i)
+// so the 16 lanes l&15 of an accumulator register walk 16 consecutive rows i of column-major C
+// and each store instruction writes four 128-byte segments.
+//
+// Tile order: the host builds a table of the active tiles (all, or the lower triangle) in
+// 8 x 8-tile patches; workgroup ids are remapped so that each XCD (ids equal mod 8 share an
+// XCD and its L2) walks one contiguous chunk of the table: the 64 tiles resident on an XCD
+// share 8 X panels and 8 Y panels.
+#include <map>
+
+#include "common.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+namespace {
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 144, NTHREADS = 256;
+constexpr int TILE_DOUBLES = BK * LDT;
+
+struct KArgs {
+    GemmArgs g;
+    const int32_t* table;
+    int32_t ntiles;
+    int32_t fast_ok;  // pointers / leading dimensions allow 16-byte loads
+};
+
+template <bool GUARD>
+__device__ __forceinline__ void load_stage(const double* __restrict__ P, int64_t ld, int64_t r0,
+                                           int64_t R, int64_t k0, int64_t K,
+                                           const double* __restrict__ s, double2_t (&regs)[4],
+                                           int tid) {
+    const int col = (tid & 63) * 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t k = k0 + r * 4 + (tid >> 6);
+        double2_t v;
+        if (GUARD) {
+            v.x = 0.0;
+            v.y = 0.0;
+            if (k < K) {
+                const double* p = P + k * ld + r0 + col;
+                if (r0 + col < R) v.x = p[0];
+                if (r0 + col + 1 < R) v.y = p[1];
+                if (s) {
+                    const double sk = s[k];
+                    v.x *= sk;
+                    v.y *= sk;
+                }
+            }
+        } else {
+            v = *reinterpret_cast<const double2_t*>(P + k * ld + r0 + col);
+            if (s) {
+                const double sk = s[k];
+                v.x *= sk;
+                v.y *= sk;
+            }
+        }
+        regs[r] = v;
+    }
+}
+
+__device__ __forceinline__ void store_stage(double* __restrict__ T, const double2_t (&regs)[4],
+                                            int tid) {
+    const int col = (tid & 63) * 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kr = r * 4 + (tid >> 6);
+        *reinterpret_cast<double2_t*>(T + kr * LDT + col) = regs[r];
+    }
+}
+
+__device__ __forceinline__ void compute_stage(const double* __restrict__ Xs,
+                                              const double* __restrict__ Ys, int wi, int wj,
+                                              int lane, double4_t (&acc)[4][4]) {
+    const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int kr = kk * 4 + hi;
+        double a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = Ys[kr * LDT + wj * 64 + t * 16 + lo];
+            b[t] = Xs[kr * LDT + wi * 64 + t * 16 + lo];
+        }
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tj], b[ti], acc[ti][tj], 0, 0, 0);
+    }
+}
+
+template <bool GUARD>
+__device__ __forceinline__ void mainloop(const GemmArgs& g, int64_t i0, int64_t j0, double* lds,
+                                         int tid, int wi, int wj, int lane,
+                                         double4_t (&acc)[4][4]) {
+    double* Xs = lds;                     // [2][BK][LDT]
+    double* Ys = lds + 2 * TILE_DOUBLES;  // [2][BK][LDT]
+    const int64_t nstage = (g.K + BK - 1) / BK;
+    double2_t xr[4], yr[4];
+    if (nstage > 0) {
+        load_stage<GUARD>(g.X, g.ldx, i0, g.M, 0, g.K, nullptr, xr, tid);
+        load_stage<GUARD>(g.Y, g.ldy, j0, g.N, 0, g.K, g.s, yr, tid);
+        store_stage(Xs, xr, tid);
+        store_stage(Ys, yr, tid);
+    }
+    __syncthreads();
+    for (int64_t st = 0; st < nstage; ++st) {
+        const int buf = (int)(st & 1);
+        const bool more = st + 1 < nstage;
+        if (more) {
+            load_stage<GUARD>(g.X, g.ldx, i0, g.M, (st + 1) * BK, g.K, nullptr, xr, tid);
+            load_stage<GUARD>(g.Y, g.ldy, j0, g.N, (st + 1) * BK, g.K, g.s, yr, tid);
+        }
+        compute_stage(Xs + buf * TILE_DOUBLES, Ys + buf * TILE_DOUBLES, wi, wj, lane, acc);
+        if (more) {
+            store_stage(Xs + (buf ^ 1) * TILE_DOUBLES, xr, tid);
+            store_stage(Ys + (buf ^ 1) * TILE_DOUBLES, yr, tid);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
+    __shared__ __attribute__((aligned(16))) double lds[4 * TILE_DOUBLES];
+    const GemmArgs& g = ka.g;
+    // XCD-contiguous remap of the workgroup id (bijective for any grid size)
+    const int bid = blockIdx.x, T = ka.ntiles;
+    const int xcd = bid & 7, q = T >> 3, r = T & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int32_t packed = ka.table[t];
+    const int64_t i0 = (int64_t)(packed >> 16) * BM;
+    const int64_t j0 = (int64_t)(packed & 0xFFFF) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    const bool interior = ka.fast_ok && (i0 + BM <= g.M) && (j0 + BN <= g.N) && (g.K % BK == 0);
+    if (interior)
+        mainloop<false>(g, i0, j0, lds, tid, wi, wj, lane, acc);
+    else
+        mainloop<true>(g, i0, j0, lds, tid, wi, wj, lane, acc);
+
+    const int lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+        const int64_t gi = i0 + wi * 64 + ti * 16 + lo;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t gj = j0 + wj * 64 + tj * 16 + hi + 4 * v;
+                if (gi < g.M && gj < g.N && (!g.lower_only || gi + g.diag_off >= gj)) {
+                    double val = g.alpha * acc[ti][tj][v];
+                    if (g.Cin) val += g.beta * g.Cin[gi + gj * g.ldcin];
+                    if (g.dvec && gi + g.diag_off == gj) val += g.dvec[gj];
+                    g.C[gi + gj * g.ldc] = val;
+                }
+            }
+        }
+    }
+}
+
+struct TableKey {
+    int64_t tm, tn, lower, doff;
+    bool operator<(const TableKey& o) const {
+        if (tm != o.tm) return tm < o.tm;
+        if (tn != o.tn) return tn < o.tn;
+        if (lower != o.lower) return lower < o.lower;
+        return doff < o.doff;
+    }
+};
+struct TableVal {
+    int32_t* d;
+    int32_t n;
+};
+// per-context cache of tile tables (contexts are used by one host thread at a time)
+std::map<madqp_ctx*, std::map<TableKey, TableVal>>& table_cache() {
+    static std::map<madqp_ctx*, std::map<TableKey, TableVal>> c;
+    return c;
+}
+}  // namespace
+
+void madqp_gemm_release_tables(madqp_ctx* ctx) {
+    auto& all = table_cache();
+    auto it = all.find(ctx);
+    if (it == all.end()) return;
+    for (auto& kv : it->second) (void)hipFree(kv.second.d);
+    all.erase(it);
+}
+
+int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls) {
+    ARG_TRY(ctx, a.M >= 0 && a.N >= 0 && a.K >= 0 && a.X && a.Y && a.C);
+    if (a.M == 0 || a.N == 0) return MADQP_OK;
+    const int64_t tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    ARG_TRY(ctx, tiles_m < 65536 && tiles_n < 32768);
+    // diag_off in tile units must be exact for the tile-skip test used when building the table
+    TableKey key{tiles_m, tiles_n, a.lower_only ? 1 : 0, a.lower_only ? a.diag_off : 0};
+    auto& cache = table_cache()[ctx];
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        std::vector<int32_t> tab;
+        tab.reserve((size_t)tiles_m * tiles_n);
+        constexpr int64_t P = 8;  // patch of P x P tiles
+        for (int64_t pm = 0; pm < tiles_m; pm += P)
+            for (int64_t pn = 0; pn < tiles_n; pn += P)
+                for (int64_t tn = pn; tn < pn + P && tn < tiles_n; ++tn)
+                    for (int64_t tm = pm; tm < pm + P && tm < tiles_m; ++tm) {
+                        // tile holds an element with i + diag_off >= j ?
+                        if (a.lower_only && (tm * BM + BM - 1 + a.diag_off < tn * BN)) continue;
+                        tab.push_back((int32_t)((tm << 16) | tn));
+                    }
+        TableVal v{nullptr, (int32_t)tab.size()};
+        if (!tab.empty()) {
+            HIP_TRY(ctx, hipMalloc(&v.d, tab.size() * sizeof(int32_t)));
+            HIP_TRY(ctx, hipMemcpyAsync(v.d, tab.data(), tab.size() * sizeof(int32_t),
+                                        hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        it = cache.emplace(key, v).first;
+    }
+    if (it->second.n == 0) return MADQP_OK;
+    KArgs ka;
+    ka.g = a;
+    ka.table = it->second.d;
+    ka.ntiles = it->second.n;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    ka.fast_ok = al16(a.X) && al16(a.Y) && (a.ldx % 2 == 0) && (a.ldy % 2 == 0);
+    ProfScope ps(ctx, prof_cls);
+    hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3(ka.ntiles), dim3(NTHREADS), 0, ctx->stream, ka);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B,
+                                       int64_t ldb, const double* w, const double* base,
+                                       int64_t ldbase, const double* dvec, double* C,
+                                       int64_t ldc) {
+    ARG_TRY(ctx, ctx != nullptr);
+    ARG_TRY(ctx, n >= 0 && kdim >= 0 && C && ldc >= n && (kdim == 0 || (B && ldb >= n)));
+    ARG_TRY(ctx, !base || ldbase >= n);
+    GemmArgs g{};
+    g.X = B ? B : C;  // K == 0: never dereferenced
+    g.ldx = ldb;
+    g.Y = g.X;
+    g.ldy = ldb;
+    g.s = w;
+    g.C = C;
+    g.ldc = ldc;
+    g.Cin = base;
+    g.ldcin = ldbase;
+    g.dvec = dvec;
+    g.alpha = 1.0;
+    g.beta = 1.0;
+    g.M = n;
+    g.N = n;
+    g.K = kdim;
+    g.diag_off = 0;
+    g.lower_only = 1;
+    return madqp_gemm_tn(ctx, g, MADQP_PROF_SYRK);
+}

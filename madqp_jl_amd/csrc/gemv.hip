@@ -1,0 +1,229 @@
+// HBM-bound dense mat-vec kernels (row r of the operand is contiguous: A[r*lda + c]).
+//
+// Replace mul!(y, kkt.AT, x) / mul!(y, kkt.AT', x) of the reference (src/KKT/normalkkt.jl:162-164,
+// 194,200,214-215), the H x / A x products of the model callbacks (scripts/qp_gpu.jl:29-40) and the
+// off-diagonal updates of the triangular sweeps (chol.hip).  Algorithmic traffic: 8*rows*cols bytes.
+//
+//   trans = 0 : y_r = alpha * sum_c A[r,c] x_c + beta * y_r   one wave (many rows) or one workgroup
+//                                                              (few long rows) per row, 16-byte loads
+//   trans = 1 : y_c = alpha * sum_r A[r,c] x_r + beta * y_c   workgroup = 128 columns x a row chunk,
+//                                                              the 4 waves stride the rows; chunk
+//                                                              partials are combined by a second
+//                                                              kernel in a fixed order (deterministic)
+#include <algorithm>
+
+#include "common.h"
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+namespace {
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ double row_dot(const double* __restrict__ a, const double* __restrict__ x,
+                                          int64_t cols, int t, int nt) {
+    double acc0 = 0.0, acc1 = 0.0;
+    if (VEC) {
+        const int64_t pairs = cols >> 1;
+#pragma unroll 4
+        for (int64_t p = t; p < pairs; p += nt) {
+            const double2_t av = *reinterpret_cast<const double2_t*>(a + 2 * p);
+            const double2_t xv = *reinterpret_cast<const double2_t*>(x + 2 * p);
+            acc0 = fma(av.x, xv.x, acc0);
+            acc1 = fma(av.y, xv.y, acc1);
+        }
+        if ((cols & 1) && t == 0) acc0 = fma(a[cols - 1], x[cols - 1], acc0);
+    } else {
+#pragma unroll 4
+        for (int64_t c = t; c < cols; c += nt) acc0 = fma(a[c], x[c], acc0);
+    }
+    return acc0 + acc1;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemv_n_wave_kernel(int64_t rows, int64_t cols, double alpha,
+                                                          const double* __restrict__ A, int64_t lda,
+                                                          const double* __restrict__ x, double beta,
+                                                          double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        double s = wave_sum(row_dot<VEC>(A + r * lda, x, cols, lane, 64));
+        if (lane == 0) y[r] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[r];
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemv_n_block_kernel(int64_t rows, int64_t cols, double alpha,
+                                                           const double* __restrict__ A, int64_t lda,
+                                                           const double* __restrict__ x, double beta,
+                                                           double* __restrict__ y) {
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        double s = wave_sum(row_dot<VEC>(A + r * lda, x, cols, threadIdx.x, 256));
+        if (lane == 0) part[w] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double tot = (part[0] + part[1]) + (part[2] + part[3]);
+            y[r] = (beta == 0.0) ? alpha * tot : alpha * tot + beta * y[r];
+        }
+        __syncthreads();
+    }
+}
+
+// trans = 1.  grid = (column tiles of 128, row chunks).  FINAL: single chunk, write y directly.
+template <bool VEC, bool FINAL>
+__global__ __launch_bounds__(256) void gemv_t_kernel(int64_t rows, int64_t cols, double alpha,
+                                                     const double* __restrict__ A, int64_t lda,
+                                                     const double* __restrict__ x, double beta,
+                                                     double* __restrict__ y,
+                                                     double* __restrict__ partial,
+                                                     int64_t rows_per_chunk) {
+    __shared__ double red[4][128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * 128 + 2 * lane;
+    const int64_t rb = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t re = min(rows, rb + rows_per_chunk);
+    double a0 = 0.0, a1 = 0.0;
+    if (VEC) {
+        if (c0 + 1 < cols) {
+#pragma unroll 8
+            for (int64_t r = rb + w; r < re; r += 4) {
+                const double2_t av = *reinterpret_cast<const double2_t*>(A + r * lda + c0);
+                const double xr = x[r];
+                a0 = fma(av.x, xr, a0);
+                a1 = fma(av.y, xr, a1);
+            }
+        } else if (c0 < cols) {
+            for (int64_t r = rb + w; r < re; r += 4) a0 = fma(A[r * lda + c0], x[r], a0);
+        }
+    } else {
+        const bool ok0 = c0 < cols, ok1 = c0 + 1 < cols;
+#pragma unroll 4
+        for (int64_t r = rb + w; r < re; r += 4) {
+            const double xr = x[r];
+            if (ok0) a0 = fma(A[r * lda + c0], xr, a0);
+            if (ok1) a1 = fma(A[r * lda + c0 + 1], xr, a1);
+        }
+    }
+    red[w][2 * lane] = a0;
+    red[w][2 * lane + 1] = a1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int64_t c = (int64_t)blockIdx.x * 128 + threadIdx.x;
+        if (c < cols) {
+            const double tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
+                               (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            if (FINAL)
+                y[c] = (beta == 0.0) ? alpha * tot : alpha * tot + beta * y[c];
+            else
+                partial[(int64_t)blockIdx.y * cols + c] = tot;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemv_t_reduce_kernel(int64_t cols, int nchunks, double alpha,
+                                                            const double* __restrict__ partial,
+                                                            double beta, double* __restrict__ y) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    double tot = 0.0;
+    for (int k = 0; k < nchunks; ++k) tot += partial[(int64_t)k * cols + c];
+    y[c] = (beta == 0.0) ? alpha * tot : alpha * tot + beta * y[c];
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(int64_t n, double beta, double* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = (beta == 0.0) ? 0.0 : beta * y[i];
+}
+}  // namespace
+
+int32_t madqp_gemv_impl(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t cols, double alpha,
+                        const double* A, int64_t lda, const double* x, double beta, double* y,
+                        int prof_cls) {
+    ARG_TRY(ctx, ctx != nullptr);
+    ARG_TRY(ctx, rows >= 0 && cols >= 0 && (trans == 0 || trans == 1));
+    const int64_t ylen = trans ? cols : rows, klen = trans ? rows : cols;
+    if (ylen == 0) return MADQP_OK;
+    ARG_TRY(ctx, y != nullptr);
+    if (klen == 0) {  // y = beta*y
+        ProfScope ps(ctx, prof_cls);
+        hipLaunchKernelGGL(scale_kernel, dim3((ylen + 255) / 256), dim3(256), 0, ctx->stream, ylen,
+                           beta, y);
+        LAUNCH_CHECK(ctx);
+        return MADQP_OK;
+    }
+    ARG_TRY(ctx, A && x && lda >= cols);
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (trans == 0) {
+        const bool vec = al16(A) && al16(x) && (lda % 2 == 0);
+        ProfScope ps(ctx, prof_cls);
+        if (rows >= 2048 || cols <= 1024) {
+            const int64_t blocks = std::min<int64_t>((rows + 3) / 4, 8192);
+            if (vec)
+                hipLaunchKernelGGL(gemv_n_wave_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream,
+                                   rows, cols, alpha, A, lda, x, beta, y);
+            else
+                hipLaunchKernelGGL(gemv_n_wave_kernel<false>, dim3(blocks), dim3(256), 0,
+                                   ctx->stream, rows, cols, alpha, A, lda, x, beta, y);
+        } else {
+            const int64_t blocks = std::min<int64_t>(rows, 4096);
+            if (vec)
+                hipLaunchKernelGGL(gemv_n_block_kernel<true>, dim3(blocks), dim3(256), 0,
+                                   ctx->stream, rows, cols, alpha, A, lda, x, beta, y);
+            else
+                hipLaunchKernelGGL(gemv_n_block_kernel<false>, dim3(blocks), dim3(256), 0,
+                                   ctx->stream, rows, cols, alpha, A, lda, x, beta, y);
+        }
+        LAUNCH_CHECK(ctx);
+        return MADQP_OK;
+    }
+    // trans == 1
+    const bool vec = al16(A) && (lda % 2 == 0);
+    const int64_t ctiles = (cols + 127) / 128;
+    int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>((2048 + ctiles - 1) / ctiles, rows / 64));
+    nchunks = std::min<int64_t>(nchunks, 64);
+    int64_t rpc = (rows + nchunks - 1) / nchunks;
+    rpc = (rpc + 3) / 4 * 4;
+    nchunks = (rows + rpc - 1) / rpc;
+    if (nchunks > 1) {
+        int32_t r = madqp_work_reserve(ctx, (size_t)nchunks * cols * sizeof(double));
+        if (r) return r;
+    }
+    ProfScope ps(ctx, prof_cls);
+    dim3 grid((unsigned)ctiles, (unsigned)nchunks);
+    if (nchunks == 1) {
+        if (vec)
+            hipLaunchKernelGGL((gemv_t_kernel<true, true>), grid, dim3(256), 0, ctx->stream, rows,
+                               cols, alpha, A, lda, x, beta, y, (double*)nullptr, rpc);
+        else
+            hipLaunchKernelGGL((gemv_t_kernel<false, true>), grid, dim3(256), 0, ctx->stream, rows,
+                               cols, alpha, A, lda, x, beta, y, (double*)nullptr, rpc);
+        LAUNCH_CHECK(ctx);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL((gemv_t_kernel<true, false>), grid, dim3(256), 0, ctx->stream, rows,
+                               cols, alpha, A, lda, x, beta, y, ctx->d_work, rpc);
+        else
+            hipLaunchKernelGGL((gemv_t_kernel<false, false>), grid, dim3(256), 0, ctx->stream, rows,
+                               cols, alpha, A, lda, x, beta, y, ctx->d_work, rpc);
+        LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, ctx->stream,
+                           cols, (int)nchunks, alpha, ctx->d_work, beta, y);
+        LAUNCH_CHECK(ctx);
+    }
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_gemv(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t cols,
+                              double alpha, const double* A, int64_t lda, const double* x,
+                              double beta, double* y) {
+    if (!ctx) return MADQP_ERR_ARG;
+    return madqp_gemv_impl(ctx, trans, rows, cols, alpha, A, lda, x, beta, y, MADQP_PROF_GEMV);
+}

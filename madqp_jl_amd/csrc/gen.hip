@@ -1,0 +1,58 @@
+// Position-addressable synthetic data generator, bit-identical to oracle/qp.py (integer hash +
+// Irwin-Hall-4, no transcendental functions): any tile can be produced on any GPU or on the CPU.
+#include "common.h"
+
+namespace {
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double gen_normal(uint64_t key, uint64_t idx) {
+    const uint64_t h = mix64(key + idx);
+    const int64_t g = (int64_t)(h & 0xFFFF) + (int64_t)((h >> 16) & 0xFFFF) +
+                      (int64_t)((h >> 32) & 0xFFFF) + (int64_t)(h >> 48) - 131070;
+    return (double)g * 0x1.bb67ae86627e7p-16;
+}
+__global__ __launch_bounds__(256) void gen_normal_kernel(uint64_t key, uint64_t idx0, int64_t count,
+                                                         double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        out[i] = gen_normal(key, idx0 + (uint64_t)i);
+}
+__global__ __launch_bounds__(256) void gen_wigner_kernel(uint64_t key, int64_t n, double inv_sqrt_n,
+                                                         double* __restrict__ H, int64_t ld) {
+    const int64_t total = n * n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t j = e / n, i = e % n;
+        const uint64_t lo = (uint64_t)(i < j ? i : j), hi = (uint64_t)(i < j ? j : i);
+        double v = gen_normal(key, lo * (uint64_t)n + hi) * inv_sqrt_n;
+        if (i == j) v = 3.0 + v;
+        H[i + j * ld] = v;
+    }
+}
+}  // namespace
+
+extern "C" int32_t madqp_gen_normal(madqp_ctx* ctx, uint64_t key, uint64_t idx0, int64_t count,
+                                    double* out) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, count >= 0 && (count == 0 || out));
+    if (count == 0) return MADQP_OK;
+    const int64_t blocks = std::min<int64_t>((count + 255) / 256, 65536);
+    hipLaunchKernelGGL(gen_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, key, idx0,
+                       count, out);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_gen_wigner(madqp_ctx* ctx, uint64_t key, int64_t n, double inv_sqrt_n,
+                                    double* H, int64_t ld) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, n >= 0 && (n == 0 || (H && ld >= n)));
+    if (n == 0) return MADQP_OK;
+    const int64_t blocks = std::min<int64_t>((n * n + 255) / 256, 65536);
+    hipLaunchKernelGGL(gen_wigner_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, key, n,
+                       inv_sqrt_n, H, ld);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}

@@ -1,0 +1,117 @@
+"""Host-side mirror of the MadNLP plugin surface for the MI355X path.
+
+``HIPCondensedKKTSystem`` plays the role of ``NormalKKTSystem <:
+MadNLP.AbstractKKTSystem`` (src/KKT/normalkkt.jl) and ``HIPCholeskySolver`` that
+of the ``MadNLP.AbstractLinearSolver`` it owns (``MadNLP.LapackCPUSolver`` in
+test/runtests.jl:151).  Method names follow the reference's generic functions
+(``build_kkt!`` -> ``build_kkt`` ...); all arithmetic happens in
+``libmadqp_hip.so``.  The Julia glue that binds the same C ABI is
+``julia/MadQPHIP.jl``.
+"""
+from __future__ import annotations
+
+from .backend import State
+
+
+class HIPCholeskySolver:
+    """AbstractLinearSolver contract: ctor keeps the matrix it re-reads at every
+    ``factorize`` (src/KKT/normalkkt.jl:99-101); ``solve`` is in place (:196)."""
+
+    def __init__(self, backend, kkt_handle):
+        self.be, self._kkt = backend, kkt_handle
+        self.info = 0
+
+    def introduce(self) -> str:  # MadNLP.introduce, src/solver.jl:360
+        return "madqp-hip blocked left-looking fp64 Cholesky (MFMA, gfx950)"
+
+    def factorize(self):  # MadNLP.factorize!
+        self.info = self.be.kkt_factorize(self._kkt)
+        return self
+
+    def is_factorized(self) -> bool:  # MadIPM.is_factorized, src/utils.jl:54-62
+        return self.info == 0
+
+    def is_inertia(self) -> bool:
+        return True
+
+    def inertia(self, n):  # (pos, zero, neg) of the SPD condensed matrix
+        return (n, 0, 0) if self.info == 0 else (self.info - 1, 0, 1)
+
+
+class HIPCondensedKKTSystem:
+    """Dense condensed KKT system ``K = H + Sigma_x + A' Theta A`` on the device.
+
+    Fields that MadIPM reads generically (``reg, pr_diag, du_diag, l_diag, u_diag,
+    l_lower, u_lower, ind_lb, ind_ub, linear_solver``; src/kernels.jl:135-144,
+    src/solver.jl:16-18) live in the shared :class:`State` and are exposed as
+    attributes.
+    """
+
+    def __init__(self, backend, st: State, nx, ind_ineq, H, A):
+        """``create_kkt_system`` (src/KKT/normalkkt.jl:29-126).  ``H``: (nx, nx) symmetric
+        tensor or None (LP); ``A``: (m, nx) row-major tensor; both are borrowed."""
+        self.be, self.st = backend, st
+        self.nx, self.m = int(nx), st.m
+        self.ind_ineq = [int(i) for i in ind_ineq]
+        self.ns = len(self.ind_ineq)
+        assert st.n == self.nx + self.ns
+        self.H, self.A = H, A
+        if H is not None:
+            assert H.is_contiguous() and H.shape == (nx, nx)
+        assert A.is_contiguous() and tuple(A.shape) == (self.m, self.nx)
+        self._h = backend.kkt_create(self.nx, self.m, self.ind_ineq, H, max(self.nx, 1), A,
+                                     max(self.nx, 1))
+        self.linear_solver = HIPCholeskySolver(backend, self._h)
+        self.n_factorizations = 0
+
+    def close(self):
+        if self._h is not None:
+            self.be.kkt_destroy(self._h)
+            self._h = None
+
+    # generic field access, as MadIPM does on any AbstractKKTSystem
+    reg = property(lambda s: s.st.reg)
+    pr_diag = property(lambda s: s.st.pr_diag)
+    du_diag = property(lambda s: s.st.du_diag)
+    l_diag = property(lambda s: s.st.l_diag)
+    u_diag = property(lambda s: s.st.u_diag)
+    l_lower = property(lambda s: s.st.l_lower)
+    u_lower = property(lambda s: s.st.u_lower)
+    ind_lb = property(lambda s: s.st.ind_lb)
+    ind_ub = property(lambda s: s.st.ind_ub)
+
+    def num_variables(self):  # src/KKT/normalkkt.jl:128
+        return self.st.n
+
+    def is_inertia_correct(self, num_pos, num_zero, num_neg):  # :132-134
+        return num_zero == 0 and num_pos == self.nx
+
+    def initialize(self):  # MadNLP.initialize!(kkt), :136-147
+        st, be = self.st, self.be
+        for t, v in ((st.reg, 1.0), (st.pr_diag, 1.0), (st.du_diag, 0.0), (st.l_lower, 0.0),
+                     (st.u_lower, 0.0), (st.l_diag, 1.0), (st.u_diag, 1.0)):
+            be.fill(v, t)
+
+    def jtprod(self, out, y):  # MadNLP.jtprod!, :162-164
+        self.be.kkt_jtprod(self._h, out, y)
+
+    def build_kkt(self):  # MadNLP.build_kkt!, :166-180
+        self.be.kkt_build(self._h, self.st)
+
+    def factorize_wrapper(self):
+        """MadNLP.factorize_wrapper! = build_kkt! then factorize! (src/linear_solver.jl:10)."""
+        self.build_kkt()
+        self.linear_solver.factorize()
+        self.n_factorizations += 1
+
+    def solve(self, w):  # MadNLP.solve!(kkt, w), :182-205
+        self.be.kkt_solve(self._h, self.st, w)
+        return w
+
+    def mul(self, w, v, alpha=1.0, beta=0.0):  # MadNLP.mul!, :207-219
+        self.be.kkt_mul(self._h, self.st, w, v, alpha, beta)
+        return w
+
+    def eval_model(self, q, rhs, c0) -> float:
+        """obj / grad! / cons! callbacks of the loop (src/solver.jl:166-169, 338-340)."""
+        return self.be.kkt_eval(self._h, self.st, q, rhs, c0)

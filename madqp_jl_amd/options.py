@@ -1,0 +1,55 @@
+"""Options and rule types of the MPC solver (src/utils.jl:10-48, 69-117)."""
+from __future__ import annotations
+
+
+class ConservativeStep:  # src/utils.jl:19-21
+    def __init__(self, tau=0.995):
+        self.tau = tau
+
+
+class AdaptiveStep:  # src/utils.jl:23-25
+    def __init__(self, tau_min=0.99):
+        self.tau_min = tau_min
+
+
+class MehrotraAdaptiveStep:  # src/utils.jl:27-29
+    def __init__(self, gamma_f=0.99):
+        self.gamma_f = gamma_f
+
+
+class NoRegularization:  # src/utils.jl:37
+    pass
+
+
+class FixedRegularization:  # src/utils.jl:39-42
+    def __init__(self, delta_p, delta_d):
+        self.delta_p, self.delta_d = delta_p, delta_d
+
+
+class AdaptiveRegularization:  # src/utils.jl:44-48
+    def __init__(self, delta_p, delta_d, delta_min):
+        self.delta_p, self.delta_d, self.delta_min = delta_p, delta_d, delta_min
+
+
+class IPMOptions:
+    """``IPMOptions`` with the reference defaults (src/utils.jl:69-103; tol preset :110).
+
+    ``kkt_system`` / ``linear_solver`` default to the HIP plugin types; the
+    condensed system needs ``delta_d < 0`` when the problem has equality rows.
+    """
+
+    _DEFAULTS = dict(
+        tol=1e-8, max_iter=3000, scaling=True, bound_push=1e-2, bound_fac=1e-2,
+        bound_relax_factor=1e-8, max_ncorr=0, mu_init=1e-1, mu_min=1e-11,
+        tol_linear_solve=1e-8, check_residual=False, rethrow_error=False, print_level=0,
+    )
+
+    def __init__(self, **kw):
+        for k, v in self._DEFAULTS.items():
+            setattr(self, k, v)
+        self.regularization = FixedRegularization(1e-8, 0.0)
+        self.step_rule = AdaptiveStep(0.99)
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError(f"unknown option {k!r}")  # MadNLP warns; we are strict
+            setattr(self, k, v)

@@ -1,0 +1,68 @@
+"""Dense QP held in HBM and the on-device synthetic instance generator.
+
+    min c0 + q'x + x'Hx/2   s.t.  lcon <= A x <= ucon,  lvar <= x <= uvar
+
+``H`` is a full symmetric (nx, nx) tensor (or None for an LP) and ``A`` an
+(m, nx) row-major tensor: the layouts the MFMA kernels consume directly.
+The synthetic family is the one of BASELINE.md section 3; entries are produced
+in place on the device by ``madqp_gen_*`` and are bit-identical to the CPU
+generator the tests use.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+_MASK = 0xFFFFFFFFFFFFFFFF
+STREAM_A, STREAM_H, STREAM_Q = 1, 2, 3
+
+
+def _mix64(z: int) -> int:
+    z = (z + 0x9E3779B97F4A7C15) & _MASK
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
+    return z ^ (z >> 31)
+
+
+def stream_key(seed: int, stream: int) -> int:
+    """Per-(seed, stream) generator key (host side of ``madqp_gen_normal``)."""
+    return _mix64((seed ^ ((stream * 0xD1B54A32D192ED03) & _MASK)) & _MASK)
+
+
+class DeviceQP:
+    def __init__(self, H, q, A, lvar, uvar, lcon, ucon, x0, c0=0.0, y0=None, name="qp"):
+        self.H, self.q, self.A = H, q, A
+        self.lvar, self.uvar, self.lcon, self.ucon, self.x0 = lvar, uvar, lcon, ucon, x0
+        self.c0 = float(c0)
+        self.y0 = torch.zeros_like(lcon) if y0 is None else y0
+        self.name = name
+        self.nvar, self.ncon = q.numel(), lcon.numel()
+
+    @classmethod
+    def from_numpy(cls, device, H, q, A, lvar, uvar, lcon, ucon, x0, c0=0.0, y0=None, name="qp"):
+        f = lambda a: None if a is None else torch.as_tensor(
+            np.ascontiguousarray(a, dtype=np.float64), device=device)
+        n = len(q)
+        Hn = None if (H is None or not np.any(H)) else f(H)
+        An = f(np.asarray(A, dtype=np.float64).reshape(len(lcon), n))
+        return cls(Hn, f(q), An, f(lvar), f(uvar), f(lcon), f(ucon), f(x0), c0, f(y0), name)
+
+    @classmethod
+    def synthetic(cls, backend, seed: int, n: int, m: int, family: str = "wigner"):
+        """0 <= x <= 1, 0 <= Ax <= 1, x0 = 0; A ~ N(0,1), H Wigner + 3 I (or LP)."""
+        dev = backend.device
+        A = torch.empty((m, n), dtype=torch.float64, device=dev)
+        backend.gen_normal(stream_key(seed, STREAM_A), 0, A)
+        q = torch.empty(n, dtype=torch.float64, device=dev)
+        backend.gen_normal(stream_key(seed, STREAM_Q), 0, q)
+        H = None
+        if family == "wigner":
+            H = torch.empty((n, n), dtype=torch.float64, device=dev)
+            backend.gen_wigner(stream_key(seed, STREAM_H), n, 1.0 / math.sqrt(n), H)
+        elif family != "lp":
+            raise ValueError(family)
+        z = lambda k, v: torch.full((k,), v, dtype=torch.float64, device=dev)
+        return cls(H, q, A, z(n, 0.0), z(n, 1.0), z(m, 0.0), z(m, 1.0), z(n, 0.0),
+                   name=f"synthetic-{family}-n{n}-m{m}-s{seed}")

@@ -159,7 +159,7 @@ def dummy_qp(n: int, m: int, seed: int = 1, equality_cons=()) -> DenseQP:
     The Julia fixture draws from Julia's RNG and cannot be reproduced here
     (SURVEY.md 8c); the structure is kept: ``P = G + G' + 100 I``, bidiagonal
     ``A`` (``A[j, j] = 1, A[j, j+1] = -1``), ``0 <= x <= 1``, ``0 <= Ax <= 1``,
-    rows in ``equality_cons`` become equalities at their upper bound.
+    rows in ``equality_cons`` become equalities at their lower bound (x_j = x_{j+1}).
     """
     G = gen_normal(stream_key(seed, STREAM_H), np.arange(n * n, dtype=U64)).reshape(n, n)
     H = G + G.T + 100.0 * np.eye(n)
@@ -169,7 +169,7 @@ def dummy_qp(n: int, m: int, seed: int = 1, equality_cons=()) -> DenseQP:
         A[j, j + 1] = -1.0
     lcon, ucon = np.zeros(m), np.ones(m)
     for j in equality_cons:
-        lcon[j] = ucon[j]
+        ucon[j] = lcon[j]
     return DenseQP(H, gen_q(seed, n), A, np.zeros(n), np.ones(n), lcon, ucon, np.zeros(n),
                    name=f"dummy-n{n}-m{m}")
 

@@ -1,0 +1,184 @@
+"""GPU parity: dense kernels (generator, GEMV, MFMA SYRK assembly, Cholesky, solves) through the C ABI
+against numpy / scipy (LAPACK) on the same inputs."""
+import math
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import torch
+
+from oracle import qp as Q
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, be):
+    return torch.as_tensor(np.ascontiguousarray(a), device=be.device)
+
+
+def test_generator_bit_exact(hip):
+    import madqp_jl_amd as M
+
+    seed, n, m = 20250614, 67, 29
+    A = torch.empty((m, n), dtype=torch.float64, device=hip.device)
+    hip.gen_normal(M.stream_key(seed, 1), 0, A)
+    assert M.stream_key(seed, 1) == Q.stream_key(seed, 1)
+    np.testing.assert_array_equal(A.cpu().numpy(), Q.gen_A(seed, m, n))
+    q = torch.empty(n, dtype=torch.float64, device=hip.device)
+    hip.gen_normal(M.stream_key(seed, 3), 0, q)
+    np.testing.assert_array_equal(q.cpu().numpy(), Q.gen_q(seed, n))
+    H = torch.empty((n, n), dtype=torch.float64, device=hip.device)
+    hip.gen_wigner(M.stream_key(seed, 2), n, 1.0 / math.sqrt(n), H)
+    np.testing.assert_array_equal(H.cpu().numpy(), Q.gen_H_wigner(seed, n))
+    # offset addressing: any tile can be generated independently
+    part = torch.empty(50, dtype=torch.float64, device=hip.device)
+    hip.gen_normal(M.stream_key(seed, 1), 1000, part)
+    np.testing.assert_array_equal(part.cpu().numpy(), Q.gen_A(seed, m, n).ravel()[1000:1050])
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (5, 3), (64, 130), (257, 1000), (3000, 77), (128, 5000),
+                                       (2500, 2049)])
+@pytest.mark.parametrize("trans", [0, 1])
+def test_gemv(hip, rows, cols, trans):
+    rng = np.random.default_rng(rows * 1000 + cols + trans)
+    lda = cols + (cols % 2)  # even and odd-free paths are both hit across the cases
+    if rows == 257:
+        lda = cols + 3  # odd leading dimension -> scalar path
+    A = rng.standard_normal((rows, lda))
+    x = rng.standard_normal(rows if trans else cols)
+    y = rng.standard_normal(cols if trans else rows)
+    for alpha, beta in [(1.0, 0.0), (-1.0, 1.0), (0.5, -2.0)]:
+        yd = dev(y, hip)
+        hip.gemv(trans, rows, cols, alpha, dev(A, hip), lda, dev(x, hip), beta, yd)
+        Am = A[:, :cols]
+        ref = alpha * ((Am.T @ x) if trans else (Am @ x)) + beta * y
+        scale = np.abs(Am).T @ np.abs(x) if trans else np.abs(Am) @ np.abs(x)
+        err = np.max(np.abs(yd.cpu().numpy() - ref) / (scale + np.abs(y) + 1e-300))
+        assert err < 1e-14, (rows, cols, trans, alpha, beta, err)
+
+
+def test_gemv_beta_zero_ignores_nan(hip):
+    A = dev(np.ones((4, 4)), hip)
+    y = dev(np.full(4, np.nan), hip)
+    hip.gemv(0, 4, 4, 1.0, A, 4, dev(np.ones(4), hip), 0.0, y)
+    np.testing.assert_array_equal(y.cpu().numpy(), np.full(4, 4.0))
+
+
+def _assemble_ref(B, w, base, dvec):
+    K = (B.T * w) @ B
+    if base is not None:
+        K = K + base
+    if dvec is not None:
+        K = K + np.diag(dvec)
+    return K
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (16, 4), (37, 13), (128, 16), (130, 33), (256, 64), (300, 1),
+                                 (385, 200), (1000, 333)])
+def test_syrk_assemble(hip, n, k):
+    """K = H + diag + B' W B, lower triangle only; asymmetric data catches a swapped C/D lane map."""
+    rng = np.random.default_rng(n * 7 + k)
+    B = rng.standard_normal((k, n))
+    w = rng.uniform(0.5, 2.0, k)
+    G = rng.standard_normal((n, n))
+    base = G + G.T
+    dvec = rng.uniform(1.0, 2.0, n)
+    ldc = n + 5
+    C = torch.full((n, ldc), np.nan, dtype=torch.float64, device=hip.device)  # column j = row j of the tensor
+    hip.syrk_assemble(n, k, dev(B, hip), n, dev(w, hip), dev(base, hip), n, dev(dvec, hip), C, ldc)
+    out = C.cpu().numpy()[:, :n].T  # out[i, j] = C[i + j*ldc]
+    ref = _assemble_ref(B, w, base, dvec)
+    low = np.tril_indices(n)
+    scale = (np.abs(B).T * w) @ np.abs(B) + np.abs(base) + np.diag(dvec)
+    err = np.max(np.abs(out[low] - ref[low]) / scale[low])
+    assert err < 1e-14, err
+    up = np.triu_indices(n, 1)
+    assert np.all(np.isnan(out[up])), "strict upper triangle must not be written"
+    # optional arguments
+    C2 = torch.zeros((n, n), dtype=torch.float64, device=hip.device)
+    hip.syrk_assemble(n, k, dev(B, hip), n, None, None, n, None, C2, n)
+    ref2 = B.T @ B
+    out2 = C2.cpu().numpy().T
+    assert np.max(np.abs(out2[low] - ref2[low]) / (np.abs(B).T @ np.abs(B))[low]) < 1e-14
+
+
+def _spd(n, rng, cond=1e3):
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.logspace(0, math.log10(cond), n)
+    return (Qm * ev) @ Qm.T
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 128, 129, 255, 256, 400, 1024, 1100, 2300])
+def test_cholesky_factor_and_solve(hip, n):
+    rng = np.random.default_rng(n)
+    K = _spd(n, rng)
+    K = 0.5 * (K + K.T)
+    lda = n + (3 if n % 2 else 2)
+    host = np.full((n, lda), np.nan)  # column-major lower: tensor row j = column j of K
+    host[:, :n] = np.where(np.triu(np.ones((n, n))) > 0, K.T, np.nan)
+    Kd = dev(host, hip)
+    h = hip.chol_create(n)
+    try:
+        info = hip.chol_factor(h, Kd, lda)
+        assert info == 0
+        L = np.tril(Kd.cpu().numpy()[:, :n].T)
+        Lref = sla.cholesky(K, lower=True)
+        rel = np.linalg.norm(L @ L.T - K) / np.linalg.norm(K)
+        assert rel < 1e-14 * max(1, math.sqrt(n)), rel
+        assert np.max(np.abs(L - Lref)) / np.max(np.abs(Lref)) < 1e-11
+        up = np.triu_indices(n, 1)
+        assert np.all(np.isnan(Kd.cpu().numpy()[:, :n].T[up])), "upper triangle must stay untouched"
+        b = rng.standard_normal(n)
+        bd = dev(b, hip)
+        hip.chol_solve(h, bd)
+        x = bd.cpu().numpy()
+        xref = sla.cho_solve((Lref, True), b)
+        assert np.linalg.norm(K @ x - b) / (np.linalg.norm(K) * np.linalg.norm(x)) < 1e-14
+        assert np.linalg.norm(x - xref) / np.linalg.norm(xref) < 1e-10
+    finally:
+        hip.chol_destroy(h)
+
+
+def test_cholesky_not_positive_definite_reports_column(hip):
+    """LAPACK info convention: first failing leading minor, never aborts (SURVEY 8b errors)."""
+    n = 300
+    rng = np.random.default_rng(5)
+    K = _spd(n, rng)
+    K[200, 200] = -1.0
+    Kd = dev(np.tril(K).T.copy(), hip)
+    h = hip.chol_create(n)
+    try:
+        info = hip.chol_factor(h, Kd, n)
+        ref_info = sla.lapack.dpotrf(K, lower=1)[1]
+        assert info == ref_info == 201
+    finally:
+        hip.chol_destroy(h)
+
+
+def test_cholesky_graded_ipm_like(hip):
+    """Diagonal scaling over 16 orders of magnitude (late-IPM Sigma): backward error stays at eps."""
+    n = 700
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((300, n))
+    sig = 10.0 ** rng.uniform(-8, 8, n)
+    th = 10.0 ** rng.uniform(-6, 6, 300)
+    K = (A.T * th) @ A + np.diag(sig)
+    K = 0.5 * (K + K.T)
+    Kd = dev(np.tril(K).T.copy(), hip)
+    h = hip.chol_create(n)
+    try:
+        assert hip.chol_factor(h, Kd, n) == 0
+        L = np.tril(Kd.cpu().numpy().T)
+        d = np.sqrt(np.diag(K))
+        E = (L @ L.T - K) / np.outer(d, d)  # scaled backward error
+        assert np.max(np.abs(E)) < 1e-13, np.max(np.abs(E))
+        b = rng.standard_normal(n)
+        bd = dev(b, hip)
+        hip.chol_solve(h, bd)
+        x = bd.cpu().numpy()
+        xref = sla.cho_solve(sla.cho_factor(K, lower=True), b)
+        res = np.linalg.norm((K @ x - b) / d) / np.linalg.norm(b / d)
+        res_ref = np.linalg.norm((K @ xref - b) / d) / np.linalg.norm(b / d)
+        assert res < 50 * max(res_ref, 1e-15), (res, res_ref)
+    finally:
+        hip.chol_destroy(h)

@@ -1,0 +1,188 @@
+"""GPU parity of the whole path: KKT plugin (build / factorize / solve / mul / jtprod) and the full
+Mehrotra predictor-corrector solve through the C ABI, against the CPU oracle and the golden traces.
+
+Stated tolerance: per-iteration alpha_p, alpha_d, inf_pr, inf_du within 1e-9
+(relative or absolute, whichever is looser) while mu >= 1e-4 and 1e-6 afterwards (conditioning ~ 1/mu);
+identical iteration count; objective rel 1e-9; ||x_gpu - x_cpu||inf <= 1e-7.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import madqp_jl_amd as M
+from oracle import mpc
+from oracle import qp as Q
+
+pytestmark = pytest.mark.gpu
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "traces.json")))
+
+
+def to_device(qp, be):
+    return M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon,
+                                 qp.x0, qp.c0)
+
+
+def solve_hip(qp, be, **opts):
+    opts.setdefault("regularization", M.FixedRegularization(1e-8, -1e-8))
+    s = M.MPCSolver(to_device(qp, be), be, **opts)
+    r = s.solve()
+    s.kkt.close()
+    return r
+
+
+def close(a, b, tol):
+    return abs(a - b) <= tol * max(1.0, abs(a), abs(b))
+
+
+def compare_traces(tr, ref, name):
+    assert len(tr) == len(ref), f"{name}: iteration count {len(tr) - 1} vs {len(ref) - 1}"
+    for t, r in zip(tr, ref):
+        tol = 1e-9 if min(t["mu"], r["mu"]) >= 1e-4 else 1e-6
+        for key in ("alpha_p", "alpha_d", "inf_pr", "inf_du", "inf_compl", "mu"):
+            assert close(t[key], r[key], tol), f"{name}: iter {t['k']} {key}: {t[key]!r} vs {r[key]!r}"
+
+
+CASES = {
+    "hs21": lambda: Q.hs21(),
+    "dummy_10_5": lambda: Q.dummy_qp(10, 5),
+    "dummy_50_10": lambda: Q.dummy_qp(50, 10),
+    "dummy_20_15_eq": lambda: Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)),
+    "dummy_20_15_eq_gondzio": lambda: Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)),
+    "synthetic_40_16": lambda: Q.synthetic_qp(20250614, 40, 16),
+    "synthetic_40_16_gondzio": lambda: Q.synthetic_qp(20250614, 40, 16),
+    "synthetic_lp_30_12": lambda: Q.synthetic_qp(20250615, 30, 12, "lp"),
+}
+NCORR = {"dummy_20_15_eq_gondzio": 5, "synthetic_40_16_gondzio": 3}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden_traces(hip, name):
+    g = GOLDEN[name]
+    r = solve_hip(CASES[name](), hip, max_ncorr=NCORR.get(name, 0))
+    assert r["status"] == g["status"] == M.SOLVE_SUCCEEDED
+    assert r["iter"] == g["iter"]
+    compare_traces(r["trace"], g["trace"], name)
+    assert close(r["objective"], g["objective"], 1e-9)
+    assert np.max(np.abs(r["solution"] - np.array(g["solution"]))) <= 1e-7
+
+
+def test_known_answers(hip):
+    r = solve_hip(Q.hs21(), hip)
+    assert r["status"] == M.SOLVE_SUCCEEDED
+    assert abs(r["objective"] - (-99.96)) < 1e-6 and np.allclose(r["solution"], [2.0, 0.0], atol=1e-6)
+    # simple_lp of test/runtests.jl:24-55 has an equality row: condensed form needs delta_d < 0
+    r = solve_hip(Q.simple_lp(), hip)
+    assert r["status"] == M.SOLVE_SUCCEEDED
+    assert abs(r["objective"] - 1.0) < 1e-6 and np.allclose(r["solution"], [0.5, 0.5], atol=1e-6)
+    assert abs(abs(r["multipliers"][0]) - 1.0) < 1e-5
+    with pytest.raises(ValueError):
+        M.MPCSolver(to_device(Q.simple_lp(), hip), hip)  # default delta_d = 0 with an equality row
+
+
+@pytest.mark.parametrize("n,m,ncorr", [(300, 120, 0), (300, 120, 3), (1500, 600, 0)])
+def test_synthetic_vs_oracle(hip, n, m, ncorr):
+    qp = Q.synthetic_qp(20250614 + n, n, m)
+    ref = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8),
+                    max_ncorr=ncorr)
+    r = solve_hip(qp, hip, max_ncorr=ncorr)
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
+    compare_traces(r["trace"], ref["trace"], f"synthetic {n}x{m}")
+    assert close(r["objective"], ref["objective"], 1e-9)
+    assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+    assert np.max(np.abs(r["multipliers"] - ref["multipliers"])) <= 1e-6
+
+
+@pytest.mark.parametrize("rule", ["adaptive", "conservative", "mehrotra"])
+def test_step_rules(hip, rule):
+    """test/runtests.jl:80-92: every step rule reaches SOLVE_SUCCEEDED; here also == oracle."""
+    mk = {"adaptive": (M.AdaptiveStep(0.99), mpc.AdaptiveStep(0.99)),
+          "conservative": (M.ConservativeStep(0.99), mpc.ConservativeStep(0.99)),
+          "mehrotra": (M.MehrotraAdaptiveStep(0.99), mpc.MehrotraAdaptiveStep(0.99))}[rule]
+    qp = Q.dummy_qp(10, 5)
+    r = solve_hip(qp, hip, step_rule=mk[0])
+    ref = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8),
+                    step_rule=mk[1])
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
+    compare_traces(r["trace"], ref["trace"], rule)
+
+
+@pytest.mark.parametrize("reg", ["fixed", "adaptive"])
+def test_regularizations(hip, reg):
+    """test/runtests.jl:117-135: regularized runs match the reference solution to 1e-6."""
+    qp = Q.dummy_qp(10, 5)
+    sol_ref = mpc.solve(qp, kkt_system="K2", regularization=mpc.NoRegularization())
+    r = solve_hip(qp, hip, regularization=(M.FixedRegularization(1e-8, -1e-9) if reg == "fixed"
+                                           else M.AdaptiveRegularization(1e-8, -1e-9, 1e-9)))
+    assert r["status"] == M.SOLVE_SUCCEEDED
+    assert abs(r["objective"] - sol_ref["objective"]) < 1e-6
+    assert np.max(np.abs(r["solution"] - sol_ref["solution"])) < 1e-6
+    assert np.max(np.abs(r["multipliers"] - sol_ref["multipliers"])) < 1e-6
+
+
+def test_kkt_system_conformance(hip):
+    """Counterpart of MadNLPTests.test_kkt_system (test/runtests.jl:149-163): build, factorize,
+    solve K x = b, then check mul!(., kkt, x) ~ b and jtprod! against the explicit Jacobian."""
+    rng = np.random.default_rng(0)
+    qp = Q.synthetic_qp(7, 90, 35)
+    qp.lcon[[3, 10]] = qp.ucon[[3, 10]] = 0.25  # two equality rows
+    s = M.MPCSolver(to_device(qp, hip), hip, regularization=M.FixedRegularization(1e-8, -1e-8))
+    s.initialize()
+    st, be = s.st, hip
+    be.set_aug_diagonal_reg(st, 1e-8, -1e-8)
+    s.kkt.factorize_wrapper()
+    assert s.kkt.linear_solver.is_factorized()
+    b = rng.standard_normal(st.ntot)
+    st.p.copy_(torch.as_tensor(b))
+    be.copy(st.p, st.d)
+    s.kkt.solve(st.d)
+    be.fill(0.0, st.w1)
+    s.kkt.mul(st.w1, st.d, 1.0, 0.0)
+    res = np.max(np.abs(st.w1.cpu().numpy() - b)) / max(1.0, np.max(np.abs(b)))
+    assert res < 1e-8, res
+    # jtprod vs explicit Jacobian [A, -I_ineq]
+    y = rng.standard_normal(st.m)
+    yd = torch.as_tensor(y, device=be.device)
+    s.kkt.jtprod(st.jacl, yd)
+    Afull = np.zeros((st.m, st.n))
+    Afull[:, : s.nx] = qp.A
+    Afull[s.ind_ineq, s.nx + np.arange(s.ns)] = -1.0
+    assert np.allclose(st.jacl.cpu().numpy(), Afull.T @ y, rtol=1e-13, atol=1e-13)
+    s.kkt.close()
+
+
+def test_factorization_failure_is_a_return_code(hip):
+    """A non positive definite K must come back as info > 0 (never abort) so that the x100
+    regularization retry of src/linear_solver.jl:11-15 can run."""
+    qp = Q.synthetic_qp(3, 200, 80)
+    s = M.MPCSolver(to_device(qp, hip), hip, regularization=M.FixedRegularization(1e-8, -1e-8))
+    s.initialize()
+    s.H.sub_(50.0 * torch.eye(200, dtype=torch.float64, device=hip.device))  # now strongly indefinite
+    s.update_regularization()
+    s.factorize_regularized_system()
+    assert s.kkt.linear_solver.info > 0
+    assert s.kkt.n_factorizations == 1 + 3  # start point + three trials
+    assert s.del_w == pytest.approx(1e-8 * 100.0 ** 3)
+    s.kkt.close()
+
+
+def test_full_size_properties_n5k(hip):
+    """BASELINE config 1 (n=5000, m=2000) is beyond what the oracle finishes in seconds:
+    size-independent properties.  The condensed solve must satisfy the UNREDUCED KKT system
+    (residual via mul!), K x = b round trip, and the solver must converge with primal/dual/
+    complementarity infeasibilities below tol."""
+    n, m = 5000, 2000
+    dq = M.DeviceQP.synthetic(hip, 20250615, n, m)
+    s = M.MPCSolver(dq, hip, regularization=M.FixedRegularization(1e-8, -1e-8), max_iter=100)
+    r = s.solve()
+    assert r["status"] == M.SOLVE_SUCCEEDED, (r["status"], r["iter"])
+    t = r["trace"][-1]
+    assert max(t["inf_pr"], t["inf_du"], t["inf_compl"]) <= 1e-8
+    assert s.last_residual_ratio < 1e-7
+    x = r["solution"]
+    assert np.all(x >= -1e-7) and np.all(x <= 1 + 1e-7)
+    Ax = (dq.A @ torch.as_tensor(x, device=hip.device)).cpu().numpy()
+    assert np.all(Ax >= -1e-6) and np.all(Ax <= 1 + 1e-6)
+    s.kkt.close()
