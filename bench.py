@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- IPM iterations/sec of the Mehrotra predictor-corrector KKT path on MI355X.
+
+Metric (BASELINE.json): IPM iterations/sec + KKT factor+solve ms, dense QP n=50k m=20k, fp64.
+A "step" is one pass of the hot path = one predictor-corrector iteration (src/solver.jl:259-343:
+residuals, Sigma update, condensed-KKT assembly (SYRK), Cholesky, two solves with residual check,
+step lengths, iterate update, model evaluation) on a synthetic dense QP generated in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nx 50000] [--m 20000]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards over independent QPs
+(BASELINE configs[3] style) -- every rank solves its own instance of the same size, no data-path
+collective, weak scaling; value = iterations of all ranks / max-over-ranks time.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F64_MFMA_TFLOPS = 78.6  # 256 CU x 2.4 GHz x 128 flop/clk/CU (MI355X datasheet fp64 matrix)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--nx", type=int, default=50000)
+    p.add_argument("--m", type=int, default=20000)
+    p.add_argument("--max-ncorr", type=int, default=0)
+    p.add_argument("--seed", type=int, default=20250614 + 1)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-nx", type=int, default=6000)
+    p.add_argument("--profile-all", action="store_true", help="time every kernel class (perturbs the "
+                   "launch-bound ones); default times only the MFMA classes")
+    return p.parse_args()
+
+
+def cpu_baseline(args, nx, m):
+    """The oracle (numpy/scipy LAPACK port of the same loop) timed on this box's host cores on a
+    bounded sample of the workload: same m/nx ratio at a smaller nx, flop-scaled to (nx, m)."""
+    import numpy as np  # noqa: F401
+
+    from oracle import mpc
+    from oracle import qp as Q
+
+    sn = min(args.cpu_sample_nx, nx)
+    sm = max(1, int(round(sn * m / nx)))
+    qp = Q.synthetic_qp(args.seed, sn, sm)
+    s = mpc.MPCSolver(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8),
+                      step_rule=mpc.AdaptiveStep(0.995), mu_min=1e-12, max_iter=300, max_ncorr=args.max_ncorr)
+    s.initialize()
+    s.iteration_head()
+    s.iteration_body()  # warm-up
+    iters, t0 = 0, time.perf_counter()
+    while iters < 3 or (time.perf_counter() - t0 < 10.0 and iters < 50):
+        if s.iteration_head() is not None:
+            break
+        s.iteration_body()
+        iters += 1
+    dt = time.perf_counter() - t0
+    flops = lambda a, b: b * a * a + a ** 3 / 3.0
+    scale = flops(sn, sm) / flops(nx, m)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    return dict(
+        value=(iters / dt) * scale, unit="IPM iterations/s", cores=cores, kind="port",
+        sample=(f"oracle/mpc.py (numpy+scipy LAPACK, all {cores} host threads) on the same synthetic "
+                f"family at nx={sn}, m={sm}: {iters} iterations in {dt:.2f} s = {iters / dt:.3f} it/s, "
+                f"scaled by the flop ratio (m nx^2 + nx^3/3) {scale:.3e} to nx={nx}, m={m}"),
+        measured_it_per_s_at_sample=iters / dt, sample_nx=sn, sample_m=sm)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import madqp_jl_amd as M
+
+    be = M.HipBackend(local_rank)
+    nx, m = args.nx, args.m
+    dq = M.DeviceQP.synthetic(be, args.seed + rank, nx, m)
+    # options of scripts/benchmarks_cpu.jl:35-44 (kkt_system -> condensed, linear_solver -> HIP Cholesky)
+    solver = M.MPCSolver(dq, be, max_iter=300, step_rule=M.AdaptiveStep(0.995),
+                         regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12,
+                         max_ncorr=args.max_ncorr, scaling=True)
+    solver.initialize()
+    excluded = 0.0  # time of re-initialisations inside the timed region (none unless it converges)
+
+    def step():
+        nonlocal excluded
+        if solver.iteration_head() is not None:  # converged: start the same instance again
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            solver.initialize()
+            solver.iteration_head()
+            torch.cuda.synchronize()
+            excluded += time.perf_counter() - t
+        solver.iteration_body()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    mfma_classes = ("syrk", "potrf_gemm", "potrf_trsm", "potrf_diag")
+    be.prof_enable(M._lib.PROF_CLASSES if args.profile_all else mfma_classes)
+    be.prof_reset()
+    excluded = 0.0
+    f0 = solver.kkt.n_factorizations
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0 - excluded
+    prof = be.prof_get()
+    be.prof_enable(())
+    nfact = solver.kkt.n_factorizations - f0
+
+    tmax = elapsed
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=be.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+
+    if rank == 0:
+        # dominant kernel: gemm_tn_f64_kernel (assembly + panel updates + panel x inverse block)
+        gemm_ms = prof["syrk"][0] + prof["potrf_gemm"][0] + prof["potrf_trsm"][0]
+        gemm_launches = prof["syrk"][1] + prof["potrf_gemm"][1] + prof["potrf_trsm"][1]
+        alg_flops = nfact * (m * nx * nx + nx ** 3 / 3.0)  # SYRK m nx^2 + POTRF nx^3/3
+        achieved = alg_flops / (gemm_ms * 1e-3) * 1e-12 if gemm_ms > 0 else 0.0
+        out = {
+            "metric": "IPM iterations/sec (Mehrotra predictor-corrector, condensed KKT + Cholesky), dense QP fp64",
+            "value": world * args.steps / tmax,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": tmax / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic dense QP nx={nx} m={m} (0<=x<=1, 0<=Ax<=1, Wigner H, Gaussian A), "
+                                   f"one independent QP per GPU, max_ncorr={args.max_ncorr}",
+                       "nx": nx, "m": m, "n_slack": m, "max_ncorr": args.max_ncorr,
+                       "options": "scripts/benchmarks_cpu.jl:35-44 with kkt_system=HIPCondensedKKTSystem, "
+                                  "linear_solver=HIPCholeskySolver"},
+            "kkt_factor_solve_ms": {
+                "assemble_syrk": prof["syrk"][0] / max(nfact, 1),
+                "factor_potrf": (prof["potrf_gemm"][0] + prof["potrf_trsm"][0] + prof["potrf_diag"][0]) / max(nfact, 1),
+                "factorizations": nfact,
+                "iteration_total": tmax / args.steps * 1e3,
+            },
+            "roofline": {
+                "bound": "mfma", "kernel": "gemm_tn_f64_kernel",
+                "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
+                "algorithmic_flops_per_launch": alg_flops / max(gemm_launches, 1),
+                "split": {k: {"ms": prof[k][0], "launches": prof[k][1]} for k in prof if prof[k][1]},
+            },
+            "iterations_done": solver.k,
+            "last_trace": {k: solver.trace[-1][k] for k in ("k", "inf_pr", "inf_du", "inf_compl", "mu")}
+            if solver.trace else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, nx, m)
+        print(json.dumps(out), flush=True)
+
+    solver.kkt.close()
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,10 +72,17 @@ enum {
     MADQP_PROF_VEC,           /* fused vector / reduction kernels        */
     MADQP_PROF_COUNT
 };
-int32_t madqp_prof_enable(madqp_ctx* ctx, int32_t on);
+/* mask: bit (1 << class) enables the timers of that class; 0 = off, 0x7F = all.  Timing the
+ * launch-bound classes (TRSV, VEC) perturbs them; the MFMA classes are safe to time always. */
+int32_t madqp_prof_enable(madqp_ctx* ctx, int32_t mask);
 int32_t madqp_prof_reset(madqp_ctx* ctx);
 /* total device milliseconds and launch count of a class since the last reset (syncs) */
 int32_t madqp_prof_get(madqp_ctx* ctx, int32_t cls, double* ms_host, int64_t* launches_host);
+
+/* Hardware probe: back-to-back v_mfma_f64_16x16x4_f64 on every SIMD (no memory traffic);
+ * tflops_host = measured dense fp64 MFMA rate of this device, the ceiling the GEMM core is
+ * judged against. */
+int32_t madqp_probe_mfma_f64(madqp_ctx* ctx, int32_t iters, double* tflops_host);
 
 /* ------------------------------------------------------------ synthetic data */
 /* out[i] = g(key, idx0 + i): the position-addressable generator of oracle/qp.py */

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "madqp_prof_enable": [vp, i32],
     "madqp_prof_reset": [vp],
     "madqp_prof_get": [vp, i32, pf64, pi64],
+    "madqp_probe_mfma_f64": [vp, i32, pf64],
     "madqp_gen_normal": [vp, C.c_uint64, C.c_uint64, i64, vp],
     "madqp_gen_wigner": [vp, C.c_uint64, i64, f64, vp, i64],
     "madqp_syrk_assemble": [vp, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64],

@@ -108,8 +108,17 @@ class HipBackend:
         self._ck(self.lib.madqp_ctx_sync(self.ctx))
 
     # ---- profiling ----
-    def prof_enable(self, on=True):
-        self._ck(self.lib.madqp_prof_enable(self.ctx, 1 if on else 0))
+    def prof_enable(self, classes=_lib.PROF_CLASSES):
+        """Enable the device timers of the named kernel classes (empty = off)."""
+        mask = 0
+        for c in classes or ():
+            mask |= 1 << _lib.PROF_CLASSES.index(c)
+        self._ck(self.lib.madqp_prof_enable(self.ctx, mask))
+
+    def probe_mfma_f64(self, iters=20000) -> float:
+        out = C.c_double()
+        self._ck(self.lib.madqp_probe_mfma_f64(self.ctx, iters, C.byref(out)))
+        return out.value
 
     def prof_reset(self):
         self._ck(self.lib.madqp_prof_reset(self.ctx))

@@ -30,7 +30,7 @@ struct madqp_ctx {
     double* d_work = nullptr;
     size_t work_bytes = 0;
     // profiling
-    bool prof = false;
+    uint32_t prof = 0;  // bit mask of enabled MADQP_PROF_* classes
     std::vector<ProfEvent> pending;
     std::vector<hipEvent_t> pool;
     double prof_ms[MADQP_PROF_COUNT] = {0};
@@ -72,11 +72,12 @@ int32_t madqp_read_results(madqp_ctx* ctx, int count, double* out_host);
 
 struct ProfScope {
     madqp_ctx* c;
-    ProfScope(madqp_ctx* ctx, int cls) : c(ctx) {
-        if (c->prof) madqp_prof_begin(c, cls);
+    bool on;
+    ProfScope(madqp_ctx* ctx, int cls) : c(ctx), on((ctx->prof >> cls) & 1u) {
+        if (on) madqp_prof_begin(c, cls);
     }
     ~ProfScope() {
-        if (c->prof) madqp_prof_end(c);
+        if (on) madqp_prof_end(c);
     }
 };
 

@@ -154,13 +154,13 @@ static int32_t prof_drain(madqp_ctx* ctx) {
     return MADQP_OK;
 }
 
-extern "C" int32_t madqp_prof_enable(madqp_ctx* ctx, int32_t on) {
+extern "C" int32_t madqp_prof_enable(madqp_ctx* ctx, int32_t mask) {
     ARG_TRY(ctx, ctx != nullptr);
-    if (!on && ctx->prof) {
+    if (!mask && ctx->prof) {
         int32_t r = prof_drain(ctx);
         if (r) return r;
     }
-    ctx->prof = on != 0;
+    ctx->prof = (uint32_t)mask;
     return MADQP_OK;
 }
 

@@ -286,3 +286,45 @@ extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, 
     g.lower_only = 1;
     return madqp_gemm_tn(ctx, g, MADQP_PROF_SYRK);
 }
+
+// ------------------------------------------------------------------ hardware probe
+namespace {
+__global__ __launch_bounds__(256) void mfma_f64_probe_kernel(int iters, double* sink) {
+    double4_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) sink[0] = s;  // keep the chain alive
+}
+}  // namespace
+
+extern "C" int32_t madqp_probe_mfma_f64(madqp_ctx* ctx, int32_t iters, double* tflops_host) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, iters > 0 && tflops_host);
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int blocks = prop.multiProcessorCount * 2;  // two 256-thread workgroups per CU
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_f64_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, 64, ctx->d_res);
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(mfma_f64_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, iters, ctx->d_res);
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2048.0;
+    *tflops_host = flops / (ms * 1e-3) * 1e-12;
+    return MADQP_OK;
+}

@@ -1,0 +1,132 @@
+"""CPU: the product's host logic (madqp_jl_amd/solver.py, kkt.py, options.py, qp.py) driven through the
+numpy test double of the C ABI (tests/fake_backend.py), compared with the oracle.  Covers control flow
+the GPU-less container can check: loop order, regularization retry, step rules, Gondzio, scaling."""
+import numpy as np
+import pytest
+import torch
+
+import madqp_jl_amd as M
+from fake_backend import FakeBackend
+from oracle import mpc
+from oracle import qp as Q
+
+
+def run(qp, be=None, **opts):
+    opts.setdefault("regularization", M.FixedRegularization(1e-8, -1e-8))
+    dq = M.DeviceQP.from_numpy("cpu", qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
+    s = M.MPCSolver(dq, be or FakeBackend(), **opts)
+    return s, s.solve()
+
+
+def oracle(qp, **opts):
+    opts.setdefault("regularization", mpc.FixedRegularization(1e-8, -1e-8))
+    return mpc.solve(qp, kkt_system="condensed", **opts)
+
+
+def assert_same_trace(r, ref, tol=1e-7):
+    assert r["status"] == ref["status"] and r["iter"] == ref["iter"]
+    for a, b in zip(r["trace"], ref["trace"]):
+        for k in ("alpha_p", "alpha_d", "inf_pr", "inf_du", "inf_compl", "mu"):
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(b[k])), (a["k"], k, a[k], b[k])
+
+
+@pytest.mark.parametrize("make,ncorr", [
+    (lambda: Q.hs21(), 0), (lambda: Q.simple_lp(), 0), (lambda: Q.dummy_qp(10, 5), 0),
+    (lambda: Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)), 5),
+    (lambda: Q.synthetic_qp(20250614, 60, 24), 0), (lambda: Q.synthetic_qp(20250614, 60, 24), 3),
+    (lambda: Q.synthetic_qp(20250615, 30, 12, "lp"), 0),
+])
+def test_driver_matches_oracle(make, ncorr):
+    qp = make()
+    _, r = run(qp, max_ncorr=ncorr)
+    ref = oracle(qp, max_ncorr=ncorr)
+    assert r["status"] == M.SOLVE_SUCCEEDED
+    assert_same_trace(r, ref)
+    assert abs(r["objective"] - ref["objective"]) <= 1e-9 * max(1, abs(ref["objective"]))
+    assert np.max(np.abs(r["solution"] - ref["solution"])) < 1e-7
+
+
+@pytest.mark.parametrize("rule", ["ConservativeStep", "AdaptiveStep", "MehrotraAdaptiveStep"])
+def test_step_rules(rule):
+    qp = Q.dummy_qp(10, 5)
+    _, r = run(qp, step_rule=getattr(M, rule)(0.99))
+    ref = oracle(qp, step_rule=getattr(mpc, rule)(0.99))
+    assert r["status"] == M.SOLVE_SUCCEEDED
+    assert_same_trace(r, ref)
+
+
+def test_adaptive_regularization_schedule():
+    qp = Q.dummy_qp(10, 5)
+    _, r = run(qp, regularization=M.AdaptiveRegularization(1e-8, -1e-9, 1e-9))
+    ref = oracle(qp, regularization=mpc.AdaptiveRegularization(1e-8, -1e-9, 1e-9))
+    assert_same_trace(r, ref)
+
+
+def test_scaling_path():
+    """MadNLP.set_scaling! (src/solver.jl:148-159): rows > 100 and gradient > 100 get scaled."""
+    qp = Q.synthetic_qp(4, 30, 12)
+    qp.A[3] *= 1000.0
+    qp.ucon[3] *= 1000.0
+    qp.q *= 400.0
+    qp.H *= 400.0
+    s, r = run(qp)
+    ref = oracle(qp)
+    assert s.obj_scale < 1.0 and float(s.con_scale[3]) < 1.0
+    assert r["status"] == M.SOLVE_SUCCEEDED
+    assert_same_trace(r, ref)
+    assert abs(r["objective"] - ref["objective"]) <= 1e-8 * max(1, abs(ref["objective"]))
+    assert np.max(np.abs(r["multipliers"] - ref["multipliers"])) < 1e-5
+
+
+def test_regularization_retry():
+    """src/linear_solver.jl:6-17: a failed factorization multiplies both regularizations by 100,
+    at most 3 trials, and does not raise."""
+    qp = Q.dummy_qp(10, 5)
+    be = FakeBackend()
+    dq = M.DeviceQP.from_numpy("cpu", qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0)
+    s = M.MPCSolver(dq, be, regularization=M.FixedRegularization(1e-8, -1e-8))
+    s.initialize()
+    n0 = s.kkt.n_factorizations
+    s.update_regularization()
+    be.fail_factorizations = 2
+    s.factorize_regularized_system()
+    assert s.kkt.n_factorizations == n0 + 3 and s.kkt.linear_solver.is_factorized()
+    assert s.del_w == pytest.approx(1e-8 * 1e4) and s.del_c == pytest.approx(-1e-8 * 1e4)
+    s.update_regularization()
+    be.fail_factorizations = 5
+    s.factorize_regularized_system()  # all three trials fail: the loop just ends (no exception)
+    assert not s.kkt.linear_solver.is_factorized()
+
+
+def test_nan_residual_raises_solve_exception():
+    """src/linear_solver.jl:41-43 -> ERROR_IN_STEP_COMPUTATION (src/solver.jl:381-383)."""
+    qp = Q.dummy_qp(10, 5)
+    dq = M.DeviceQP.from_numpy("cpu", qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0)
+    s = M.MPCSolver(dq, FakeBackend(), regularization=M.FixedRegularization(1e-8, -1e-8))
+    s.initialize()
+    s.st.f[0] = float("nan")
+    s.update_regularization()
+    s.factorize_regularized_system()
+    with pytest.raises(M.SolveException):
+        s.affine_direction()
+
+
+def test_equality_rows_need_negative_delta_d():
+    qp = Q.simple_lp()
+    dq = M.DeviceQP.from_numpy("cpu", qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0)
+    with pytest.raises(ValueError):
+        M.MPCSolver(dq, FakeBackend())
+    with pytest.raises(TypeError):
+        M.MPCSolver(dq, FakeBackend(), no_such_option=1)
+
+
+def test_stream_keys_match_the_oracle_generator():
+    for seed in (0, 1, 20250614, 2**63 + 5):
+        for stream in (1, 2, 3):
+            assert M.stream_key(seed, stream) == Q.stream_key(seed, stream)
+
+
+def test_max_iter_status():
+    qp = Q.dummy_qp(10, 5)
+    _, r = run(qp, max_iter=2)
+    assert r["status"] == M.MAXIMUM_ITERATIONS_EXCEEDED and r["iter"] == 2

@@ -1,0 +1,156 @@
+"""CPU: pins the oracle (oracle/mpc.py).  The reference holds no golden vectors, so
+the pins are known answers, an independent LP solver (HiGHS), the cross-formulation equalities the
+reference itself asserts (test/runtests.jl:102-115,165-180) and the committed traces."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.optimize as so
+
+from oracle import mpc
+from oracle import qp as Q
+
+REG = lambda: mpc.FixedRegularization(1e-8, -1e-8)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_simple_lp_known_answer():
+    """test/runtests.jl:24-55,165-180: objective 1.0 at (0.5, 0.5); |y| = 1; all formulations agree."""
+    ref = mpc.solve(Q.simple_lp(), kkt_system="K2", regularization=mpc.NoRegularization())
+    assert ref["status"] == mpc.SOLVE_SUCCEEDED
+    assert abs(ref["objective"] - 1.0) < 1e-8 and np.allclose(ref["solution"], [0.5, 0.5], atol=1e-8)
+    assert abs(abs(ref["multipliers"][0]) - 1.0) < 1e-6
+    for kkt, reg in (("normal", mpc.FixedRegularization(1e-8, 0.0)), ("condensed", REG())):
+        r = mpc.solve(Q.simple_lp(), kkt_system=kkt, regularization=reg)
+        assert r["status"] == mpc.SOLVE_SUCCEEDED
+        assert abs(r["objective"] - ref["objective"]) < 1e-6
+        assert np.allclose(r["solution"], ref["solution"], atol=1e-6)
+        assert np.allclose(r["multipliers"], ref["multipliers"], atol=1e-5)
+
+
+def test_hs21_known_answer():
+    for kkt in ("K2", "condensed"):
+        r = mpc.solve(Q.hs21(), kkt_system=kkt, regularization=REG())
+        assert r["status"] == mpc.SOLVE_SUCCEEDED
+        assert abs(r["objective"] + 99.96) < 1e-7 and np.allclose(r["solution"], [2.0, 0.0], atol=1e-7)
+
+
+def test_normal_kkt_rejects_qp():
+    """src/KKT/normalkkt.jl:45-48."""
+    with pytest.raises(ValueError):
+        mpc.MPCSolver(Q.hs21(), kkt_system="normal")
+
+
+@pytest.mark.parametrize("n,m", [(10, 0), (10, 5), (50, 10)])
+@pytest.mark.parametrize("ncorr", [0, 5])
+def test_k2_equals_condensed_dummy(n, m, ncorr):
+    """test/runtests.jl:57-73,102-115 in spirit: same iteration count, objective, x, multipliers."""
+    qp = Q.dummy_qp(n, m)
+    a = mpc.solve(qp, kkt_system="K2", regularization=REG(), max_ncorr=ncorr)
+    b = mpc.solve(qp, kkt_system="condensed", regularization=REG(), max_ncorr=ncorr)
+    assert a["status"] == b["status"] == mpc.SOLVE_SUCCEEDED and a["iter"] == b["iter"]
+    assert abs(a["objective"] - b["objective"]) < 1e-9
+    assert np.allclose(a["solution"], b["solution"], atol=1e-8)
+    assert np.allclose(a["multipliers"], b["multipliers"], atol=1e-6)
+    # KKT conditions of the QP itself
+    x, y = a["solution"], a["multipliers"]
+    g = qp.H @ x + qp.q + qp.A.T @ y - a["multipliers_L"] + a["multipliers_U"]
+    assert np.max(np.abs(g)) < 1e-6
+
+
+def test_equality_rows_condensed():
+    qp = Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7))
+    a = mpc.solve(qp, kkt_system="K2", regularization=REG())
+    b = mpc.solve(qp, kkt_system="condensed", regularization=REG())
+    assert a["status"] == b["status"] == mpc.SOLVE_SUCCEEDED and a["iter"] == b["iter"]
+    assert np.allclose(a["solution"], b["solution"], atol=1e-7)
+    assert np.max(np.abs((qp.A @ a["solution"])[[0, 1, 2, 7]])) < 1e-7
+    with pytest.raises(ValueError):  # delta_d = 0: equality rows are not representable
+        mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, 0.0))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_lp_against_highs(seed):
+    qp = Q.synthetic_qp(seed, 30, 12, "lp")
+    hi = so.linprog(qp.q, A_ub=np.vstack([qp.A, -qp.A]), b_ub=np.concatenate([qp.ucon, -qp.lcon]),
+                    bounds=list(zip(qp.lvar, qp.uvar)), method="highs")
+    assert hi.status == 0
+    for kkt, reg in (("K2", REG()), ("normal", mpc.FixedRegularization(1e-8, 0.0)), ("condensed", REG())):
+        r = mpc.solve(qp, kkt_system=kkt, regularization=reg)
+        assert r["status"] == mpc.SOLVE_SUCCEEDED, kkt
+        assert abs(r["objective"] - hi.fun) < 1e-6 * max(1, abs(hi.fun)), (kkt, r["objective"], hi.fun)
+
+
+@pytest.mark.parametrize("rule", [mpc.AdaptiveStep(0.99), mpc.ConservativeStep(0.99),
+                                  mpc.MehrotraAdaptiveStep(0.99)])
+def test_step_rules(rule):
+    """test/runtests.jl:80-92."""
+    r = mpc.solve(Q.dummy_qp(10, 5), kkt_system="condensed", regularization=REG(), step_rule=rule)
+    assert r["status"] == mpc.SOLVE_SUCCEEDED
+
+
+@pytest.mark.parametrize("reg", [lambda: mpc.FixedRegularization(1e-8, -1e-9),
+                                 lambda: mpc.AdaptiveRegularization(1e-8, -1e-9, 1e-9)])
+def test_regularizations(reg):
+    """test/runtests.jl:117-135."""
+    qp = Q.dummy_qp(10, 5)
+    ref = mpc.solve(qp, kkt_system="K2", regularization=mpc.NoRegularization())
+    r = mpc.solve(qp, kkt_system="condensed", regularization=reg())
+    assert r["status"] == mpc.SOLVE_SUCCEEDED
+    assert abs(r["objective"] - ref["objective"]) < 1e-6
+    assert np.allclose(r["solution"], ref["solution"], atol=1e-6)
+    assert np.allclose(r["multipliers"], ref["multipliers"], atol=1e-6)
+
+
+def test_kkt_solve_mul_consistency():
+    """MadNLPTests.test_kkt_system in spirit (test/runtests.jl:149-163): K * solve(b) == b for the
+    UNREDUCED system, for every formulation."""
+    rng = np.random.default_rng(0)
+    qp = Q.synthetic_qp(5, 25, 10)
+    for kkt in ("K2", "condensed"):
+        s = mpc.MPCSolver(qp, kkt_system=kkt, regularization=REG())
+        s.initialize()
+        s.update_regularization()
+        s.factorize_regularized_system()
+        b = rng.standard_normal(s.p.values.size)
+        s.p.values[:] = b
+        s.solve_system()
+        assert s.last_residual_ratio < 1e-10
+
+
+def test_aliasing_quirk_of_starting_point():
+    """src/solver.jl:80-81: x_lr and x_ur are views of the same x, so the two primal shifts cancel
+    on two-sided variables -- the start stays strictly interior."""
+    s = mpc.MPCSolver(Q.synthetic_qp(9, 12, 5), kkt_system="condensed", regularization=REG())
+    s.initialize()
+    assert np.all(s.x > s.xl) and np.all(s.x < s.xu) and np.all(s.zl_r > 0) and np.all(s.zu_r > 0)
+
+
+def test_generator_is_position_addressable():
+    A = Q.gen_A(42, 7, 11)
+    part = Q.gen_normal(Q.stream_key(42, Q.STREAM_A), np.arange(30, 50, dtype=np.uint64))
+    assert np.array_equal(part, A.ravel()[30:50])
+    H = Q.gen_H_wigner(42, 200)
+    assert np.array_equal(H, H.T)
+    ev = np.linalg.eigvalsh(H)
+    assert 0.5 < ev[0] and ev[-1] < 5.6
+    g = Q.gen_normal(Q.stream_key(1, 1), np.arange(200000, dtype=np.uint64))
+    assert abs(g.mean()) < 0.01 and abs(g.std() - 1.0) < 0.01
+
+
+def test_golden_traces_are_reproduced():
+    """The committed fixtures are exactly what tests/golden/make_golden.py produces today."""
+    golden = json.load(open(os.path.join(HERE, "golden", "traces.json")))
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+
+    assert set(golden) == set(make_golden.CASES)
+    for name in golden:
+        cur = make_golden.run(name)
+        assert cur["iter"] == golden[name]["iter"] and cur["status"] == golden[name]["status"]
+        for a, b in zip(cur["trace"], golden[name]["trace"]):
+            for k in make_golden.KEYS:
+                assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (name, a["k"], k)
