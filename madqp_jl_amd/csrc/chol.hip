@@ -23,42 +23,136 @@ constexpr int NBO = 1024;  // outer panel
 constexpr int LDS_LD = NB + 1;
 constexpr int64_t WBLK = 2 * NB * NB;  // doubles per block in chol->winv: [Wcm | Wrm]
 
-// Unblocked right-looking Cholesky of one nb x nb (nb <= 128) diagonal block held in LDS,
-// followed by the inversion of the triangular factor.  info: the first failing column
-// (1-based, LAPACK dpotrf convention) is recorded once; the block is then completed with a
-// unit pivot so that the launch always terminates.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int SB = 16;             // sub-block of the diagonal kernel (one MFMA tile)
+constexpr int NSB = NB / SB;       // 8 sub-block columns
+constexpr int WD_LD = SB + 1;      // row stride of the inverse diagonal sub-blocks
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave: Cholesky of the 16 x 16 sub-block at (b, b) of S and the inverse of its factor.
+// Lane r (= lane & 15) keeps row r of the sub-block in registers; column k is broadcast with
+// v_readlane, so the 16 elimination steps need no LDS round trip and no barrier.
+// Writes L (lower) back to S and W = L^-1 to Wd[r*WD_LD + c] (zero above the diagonal).
+__device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int b,
+                                                     double* __restrict__ Wd,
+                                                     int32_t* __restrict__ info, int32_t col0,
+                                                     int lane) {
+    const int r = lane & 15;
+    double a[SB];
+#pragma unroll
+    for (int c = 0; c < SB; ++c) a[c] = S[(b + c) * LDS_LD + b + r];
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        double akk = readlane_f64(a[k], k);
+        if (!(akk > 0.0)) {  // not positive definite (or NaN): record the first column, go on
+            if (lane == 0) atomicCAS(info, 0, col0 + b + k + 1);
+            akk = 1.0;
+        }
+        const double d = sqrt(akk);
+        const double rd = 1.0 / d;
+        const double lk = (r == k) ? d : a[k] * rd;
+        a[k] = lk;
+#pragma unroll
+        for (int c = k + 1; c < SB; ++c) {
+            const double lck = readlane_f64(lk, c);
+            a[c] -= lk * lck;
+        }
+    }
+    if (lane < SB) {
+#pragma unroll
+        for (int c = 0; c < SB; ++c)
+            if (r >= c) S[(b + c) * LDS_LD + b + r] = a[c];
+    }
+    // inverse: lane cc computes column cc of W by forward substitution over the rows
+    const int cc = r;
+    double w[SB];
+#pragma unroll
+    for (int rr = 0; rr < SB; ++rr) {
+        const double inv = 1.0 / readlane_f64(a[rr], rr);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < rr; ++k) acc += readlane_f64(a[k], rr) * w[k];
+        w[rr] = (rr == cc) ? inv : ((rr > cc) ? -(acc * inv) : 0.0);
+    }
+    if (lane < SB) {
+#pragma unroll
+        for (int rr = 0; rr < SB; ++rr) Wd[rr * WD_LD + cc] = w[rr];
+    }
+}
+
+// Cholesky of one nb x nb (nb <= 128) diagonal block, resident in LDS, and the inverse of its
+// factor -- blocked by 16 so that everything off the 16 x 16 diagonal sub-blocks is
+// v_mfma_f64_16x16x4_f64 work with operands read straight from the LDS image:
+//   for J = 0..7:  wave 0: L_JJ, W_JJ = L_JJ^-1 (registers + v_readlane)
+//                  all waves: L_IJ = A_IJ W_JJ'  (I > J),   A_IK -= L_IJ L_KJ'  (I >= K > J)
+//   then W = L^-1 block column by block column (columns are independent -> one per wave, no
+//   barrier):  W_IJ = -W_II * sum_{K=J}^{I-1} L_IK W_KJ.  The f64 accumulator layout
+//   (row = (lane>>4) + 4v) is exactly the B-operand layout (k = 4s + (lane>>4)), so the inner
+//   sum feeds the second product without leaving the registers.
+// W_IJ (I > J) is parked in the unused upper triangle at S[R*LDS_LD + C] (R > C global indices).
+// info: the first failing column (1-based, LAPACK dpotrf convention) is recorded once; the block
+// is then completed with a unit pivot so that the launch always terminates.
 // Outputs: L_jj in place; Wcm[r + c*NB] = W(r,c) (column-major) and Wrm[c + r*NB] = W(r,c)
 // (row-major), both zero padded to 128 x 128.
 __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int nb,
                                                         double* __restrict__ Wcm,
                                                         double* __restrict__ Wrm,
                                                         int32_t* __restrict__ info, int32_t col0) {
-    __shared__ double S[NB * LDS_LD];  // S[c*LDS_LD + r] = element (r, c)
-    __shared__ double dinv[NB];
-    const int tid = threadIdx.x;
+    __shared__ double S[NB * LDS_LD];           // S[c*LDS_LD + r] = element (r, c)
+    __shared__ double Wd[NSB * SB * WD_LD];     // inverse diagonal sub-blocks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
     for (int idx = tid; idx < NB * NB; idx += 256) {
         const int c = idx / NB, r = idx % NB;
         double v = 0.0;
-        if (r < nb && c < nb && r >= c) v = A[r + (int64_t)c * lda];
+        if (r < nb && c < nb) {
+            if (r >= c) v = A[r + (int64_t)c * lda];
+        } else if (r == c) {
+            v = 1.0;  // identity padding keeps the padded block positive definite
+        }
         S[c * LDS_LD + r] = v;
     }
     __syncthreads();
-    const int tx = tid & 31, ty = tid >> 5;
-    for (int k = 0; k < nb; ++k) {
-        double akk = S[k * LDS_LD + k];
-        if (!(akk > 0.0)) {  // also catches NaN
-            if (tid == 0) atomicCAS(info, 0, col0 + k + 1);
-            akk = 1.0;
-        }
-        const double d = sqrt(akk);
-        const double rd = 1.0 / d;
-        __syncthreads();  // every thread has read the pivot
-        for (int r = k + 1 + tid; r < nb; r += 256) S[k * LDS_LD + r] *= rd;
-        if (tid == 0) S[k * LDS_LD + k] = d;
+    for (int J = 0; J < NSB; ++J) {
+        const int b = J * SB;
+        double* WdJ = Wd + J * SB * WD_LD;
+        if (wave == 0) diag16_factor_invert(S, b, WdJ, info, col0, lane);
         __syncthreads();
-        for (int c = k + 1 + ty; c < nb; c += 8) {
-            const double lck = S[k * LDS_LD + c];
-            for (int r = c + tx; r < nb; r += 32) S[c * LDS_LD + r] -= S[k * LDS_LD + r] * lck;
+        // panel: L_IJ = A_IJ * W_JJ'
+        for (int I = J + 1 + wave; I < NSB; I += 4) {
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double av = S[(b + 4 * s + hi) * LDS_LD + SB * I + lo];  // A_IJ[lo][4s+hi]
+                const double bv = WdJ[lo * WD_LD + 4 * s + hi];                // W_JJ[lo][4s+hi]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) S[(b + lo) * LDS_LD + SB * I + hi + 4 * v] = acc[v];
+        }
+        __syncthreads();
+        // trailing update: A_IK -= L_IJ * L_KJ'   (J < K <= I)
+        int t = 0;
+        for (int K = J + 1; K < NSB; ++K) {
+            for (int I = K; I < NSB; ++I, ++t) {
+                if ((t & 3) != wave) continue;
+                double4_t acc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[v] = S[(SB * K + lo) * LDS_LD + SB * I + hi + 4 * v];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double av = -S[(b + 4 * s + hi) * LDS_LD + SB * I + lo];  // -L_IJ[lo][k]
+                    const double bv = S[(b + 4 * s + hi) * LDS_LD + SB * K + lo];   //  L_KJ[lo][k]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) S[(SB * K + lo) * LDS_LD + SB * I + hi + 4 * v] = acc[v];
+            }
         }
         __syncthreads();
     }
@@ -67,23 +161,36 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
         const int c = idx / nb, r = idx % nb;
         if (r >= c) A[r + (int64_t)c * lda] = S[c * LDS_LD + r];
     }
-    __syncthreads();
-    // W = L^-1, column c by thread c; entry (r, c), r > c, is parked in the unused upper part
-    // at S[r*LDS_LD + c].  Loops are wave uniform so that L[r,k] is an LDS broadcast.
-    if (tid < NB) {
-        const int c = tid;
-        const double xc = (c < nb) ? 1.0 / S[c * LDS_LD + c] : 0.0;
-        dinv[c] = xc;
-        for (int r = 1; r < nb; ++r) {
-            const double lrr = S[r * LDS_LD + r];
-            double acc = 0.0;
-            for (int k = 0; k < r; ++k) {
-                const double l = S[k * LDS_LD + r];
-                const double up = S[k * LDS_LD + c];
-                const double xk = (k > c) ? up : (k == c ? xc : 0.0);
-                acc += l * xk;
+    // W = L^-1: block columns {0}, {1,6}, {2,5,7}, {3,4} on waves 0..3 (balanced MFMA counts)
+    for (int q = 0; q < 3; ++q) {
+        int J;
+        if (q == 0)
+            J = wave;
+        else if (q == 1)
+            J = (wave == 0) ? -1 : 7 - wave;
+        else
+            J = (wave == 2) ? 7 : -1;
+        if (J < 0) continue;
+        for (int I = J + 1; I < NSB; ++I) {
+            double4_t T = {0.0, 0.0, 0.0, 0.0};
+            for (int K = J; K < I; ++K) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int k = 4 * s + hi;
+                    const double av = S[(SB * K + k) * LDS_LD + SB * I + lo];  // L_IK[lo][k]
+                    const double bv = (K == J) ? Wd[(J * SB + k) * WD_LD + lo]  // W_JJ[k][lo]
+                                               : S[(SB * K + k) * LDS_LD + SB * J + lo];  // W_KJ[k][lo]
+                    T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T, 0, 0, 0);
+                }
             }
-            if (r > c) S[r * LDS_LD + c] = -acc / lrr;
+            double4_t R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double av = Wd[(I * SB + lo) * WD_LD + 4 * s + hi];  // W_II[lo][4s+hi]
+                R = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[s], R, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) S[(SB * I + hi + 4 * v) * LDS_LD + SB * J + lo] = -R[v];
         }
     }
     __syncthreads();
@@ -91,13 +198,15 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
         {  // column-major image: idx = c*NB + r
             const int c = idx / NB, r = idx % NB;
             double v = 0.0;
-            if (r < nb && c < nb) v = (r == c) ? dinv[c] : (r > c ? S[r * LDS_LD + c] : 0.0);
+            if (r < nb && c < nb && r >= c)
+                v = (r / SB == c / SB) ? Wd[((r / SB) * SB + r % SB) * WD_LD + c % SB] : S[r * LDS_LD + c];
             Wcm[idx] = v;
         }
         {  // row-major image: idx = r*NB + c
             const int r = idx / NB, c = idx % NB;
             double v = 0.0;
-            if (r < nb && c < nb) v = (r == c) ? dinv[c] : (r > c ? S[r * LDS_LD + c] : 0.0);
+            if (r < nb && c < nb && r >= c)
+                v = (r / SB == c / SB) ? Wd[((r / SB) * SB + r % SB) * WD_LD + c % SB] : S[r * LDS_LD + c];
             Wrm[idx] = v;
         }
     }
@@ -165,6 +274,27 @@ extern "C" int32_t madqp_chol_destroy(madqp_chol* s) {
     return MADQP_OK;
 }
 
+// Width (multiple of 128, 768..2048) of the next outer panel: the wide update GEMM runs
+// (rows/128) x (W/128) tiles of equal cost on `slots` resident workgroups, so W is chosen to
+// make the last round of tiles as full as possible (tail quantisation is the main loss of a
+// left-looking factorisation; 8 fixed tile columns leave the last round 5-50 % full).
+static int64_t outer_panel_width(int64_t rows, bool has_update, int64_t slots) {
+    const int64_t mt = (rows + NB - 1) / NB;
+    if (!has_update || mt <= 6) return NBO;
+    int64_t best = NBO / NB;
+    double best_eff = -1.0;
+    for (int64_t wt = 6; wt <= 16 && wt <= mt; ++wt) {
+        const int64_t tiles = mt * wt - wt * (wt - 1) / 2;
+        const int64_t rounds = (tiles + slots - 1) / slots;
+        const double eff = (double)tiles / (double)(rounds * slots);
+        if (eff > best_eff + 1e-9 || (eff > best_eff - 0.01 && wt > best && eff > 0.97)) {
+            best_eff = std::max(eff, best_eff);
+            best = wt;
+        }
+    }
+    return best * NB;
+}
+
 static int32_t panel_update(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t row0,
                             int64_t k0, int64_t width) {
     // C[row0:n, row0:row0+width] -= L[row0:n, k0:row0] * L[row0:row0+width, k0:row0]'
@@ -201,8 +331,9 @@ extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int3
         return MADQP_OK;
     }
     HIP_TRY(ctx, hipMemsetAsync(s->d_info, 0, sizeof(int32_t), ctx->stream));
-    for (int64_t J0 = 0; J0 < n; J0 += NBO) {
-        const int64_t W = std::min<int64_t>(NBO, n - J0);
+    int64_t W = 0;
+    for (int64_t J0 = 0; J0 < n; J0 += W) {
+        W = std::min<int64_t>(outer_panel_width(n - J0, J0 > 0, ctx->gemm_slots), n - J0);
         if (J0 > 0) {
             int32_t r = panel_update(ctx, A, lda, n, J0, 0, W);
             if (r) return r;

@@ -20,6 +20,7 @@ struct ProfEvent {
 struct madqp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    int64_t gemm_slots = 512;  // resident GEMM workgroups: 2 per CU
     char err[512] = {0};
     // scalar results: device block + pinned host mirror
     double* d_res = nullptr;
@@ -29,6 +30,9 @@ struct madqp_ctx {
     // generic workspace for deterministic two-pass gemv
     double* d_work = nullptr;
     size_t work_bytes = 0;
+    // scaled copy of the assembly operand (Theta A), grow-only
+    double* d_scaled = nullptr;
+    size_t scaled_bytes = 0;
     // profiling
     uint32_t prof = 0;  // bit mask of enabled MADQP_PROF_* classes
     std::vector<ProfEvent> pending;
@@ -87,7 +91,6 @@ struct GemmArgs {
     int64_t ldx;
     const double* Y;  // Y[j + k*ldy], j in [0,N)
     int64_t ldy;
-    const double* s;  // optional per-k scale of Y (NULL = 1)
     double* C;        // out C[i + j*ldc]
     int64_t ldc;
     const double* Cin;  // optional addend, same indexing with ldcin (may alias C)

@@ -13,6 +13,11 @@ extern "C" int32_t madqp_ctx_create(int32_t device, void* stream, madqp_ctx** ou
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
     hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            ctx->gemm_slots = 2 * (int64_t)cus;
+    }
     if (e == hipSuccess) e = hipMalloc(&ctx->d_res, MADQP_RESULT_SLOTS * sizeof(double));
     if (e == hipSuccess)
         e = hipHostMalloc((void**)&ctx->h_res, MADQP_RESULT_SLOTS * sizeof(double), hipHostMallocDefault);
@@ -40,6 +45,7 @@ extern "C" int32_t madqp_ctx_destroy(madqp_ctx* ctx) {
     if (ctx->h_res) (void)hipHostFree(ctx->h_res);
     if (ctx->d_part) (void)hipFree(ctx->d_part);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
+    if (ctx->d_scaled) (void)hipFree(ctx->d_scaled);
     delete ctx;
     return MADQP_OK;
 }

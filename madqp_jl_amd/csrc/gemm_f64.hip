@@ -1,4 +1,4 @@
-// fp64 MFMA GEMM core for gfx950:  C[i,j] = alpha * sum_k X[i,k] s[k] Y[j,k] + beta * Cin[i,j] (+ dvec on the diagonal)
+// fp64 MFMA GEMM core for gfx950:  C[i,j] = alpha * sum_k X[i,k] Y[j,k] + beta * Cin[i,j] (+ dvec on the diagonal)
 //
 // One kernel serves the three dense contractions of the hot path:
 //   * condensed-KKT assembly  K = H + Sigma_x + A' Theta A          (madqp_syrk_assemble)
@@ -12,10 +12,14 @@
 //
 // Tiling: 128 x 128 output tile per 256-thread workgroup (4 waves = 2 x 2, one per SIMD), each wave
 // owns 64 x 64 = 4 x 4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  K is consumed in
-// stages of 16: global -> registers (prefetch of stage s+1 in flight while stage s computes)
-// -> LDS (double buffered, one barrier per stage).  Per stage a wave issues 64 MFMAs and only
-// 32 ds_read_b64, so the matrix pipe is the only busy resource.  LDS row stride 144 doubles
-// (= 16 mod 32) makes the two k-rows of a 32-lane ds_read_b64 group hit disjoint banks.
+// stages of 16, LDS double buffered, one barrier per stage.  Interior tiles stage with LDS-DMA
+// (global_load_lds_dwordx4: one wave instruction = one 1 KiB tile row, no VGPR round trip, no
+// ds_write); edge tiles stage through registers with bounds checks and zero fill.  Per stage a
+// wave issues 64 MFMAs and 32 ds_read_b64.  On gfx950 the fp64 MFMA shares the SIMD's issue with
+// every other vector instruction (measured: each v_fma between two MFMAs costs ~9 cycles of
+// matrix pipe, tools/mfma_probe.hip), so the loop is written to keep VALU work out of it.
+// LDS row stride 144 doubles (= 16 mod 32) makes the two k-rows of a 32-lane ds_read_b64 group
+// hit disjoint banks.
 //
 // MFMA operand roles (v_mfma_f64_16x16x4_f64: D[r][c] = sum_k A[r][k] B[k][c]; lane l feeds
 // A[l&15][l>>4] and B[l>>4][l&15]; lane l holds D[(l>>4) + 4v][l&15], v = 0..3):
@@ -27,6 +31,7 @@
 // 8 x 8-tile patches; workgroup ids are remapped so that each XCD (ids equal mod 8 share an
 // XCD and its L2) walks one contiguous chunk of the table: the 64 tiles resident on an XCD
 // share 8 X panels and 8 Y panels.
+#include <algorithm>
 #include <map>
 
 #include "common.h"
@@ -43,12 +48,15 @@ struct KArgs {
     const int32_t* table;
     int32_t ntiles;
     int32_t fast_ok;  // pointers / leading dimensions allow 16-byte loads
+#ifdef MADQP_STAMPS
+    unsigned long long* stamps;  // diagnostic build only (tools/gemm_probe): per-workgroup clocks
+#endif
 };
 
+// register-staged loader (edge tiles, unaligned operands): bounds checks and zero fill
 template <bool GUARD>
 __device__ __forceinline__ void load_stage(const double* __restrict__ P, int64_t ld, int64_t r0,
-                                           int64_t R, int64_t k0, int64_t K,
-                                           const double* __restrict__ s, double2_t (&regs)[4],
+                                           int64_t R, int64_t k0, int64_t K, double2_t (&regs)[4],
                                            int tid) {
     const int col = (tid & 63) * 2;
 #pragma unroll
@@ -62,19 +70,9 @@ __device__ __forceinline__ void load_stage(const double* __restrict__ P, int64_t
                 const double* p = P + k * ld + r0 + col;
                 if (r0 + col < R) v.x = p[0];
                 if (r0 + col + 1 < R) v.y = p[1];
-                if (s) {
-                    const double sk = s[k];
-                    v.x *= sk;
-                    v.y *= sk;
-                }
             }
         } else {
             v = *reinterpret_cast<const double2_t*>(P + k * ld + r0 + col);
-            if (s) {
-                const double sk = s[k];
-                v.x *= sk;
-                v.y *= sk;
-            }
         }
         regs[r] = v;
     }
@@ -111,17 +109,17 @@ __device__ __forceinline__ void compute_stage(const double* __restrict__ Xs,
     }
 }
 
-template <bool GUARD>
-__device__ __forceinline__ void mainloop(const GemmArgs& g, int64_t i0, int64_t j0, double* lds,
-                                         int tid, int wi, int wj, int lane,
-                                         double4_t (&acc)[4][4]) {
+// edge tiles: global -> registers -> LDS
+__device__ __forceinline__ void mainloop_staged(const GemmArgs& g, int64_t i0, int64_t j0, double* lds,
+                                                int tid, int wi, int wj, int lane,
+                                                double4_t (&acc)[4][4]) {
     double* Xs = lds;                     // [2][BK][LDT]
     double* Ys = lds + 2 * TILE_DOUBLES;  // [2][BK][LDT]
     const int64_t nstage = (g.K + BK - 1) / BK;
     double2_t xr[4], yr[4];
     if (nstage > 0) {
-        load_stage<GUARD>(g.X, g.ldx, i0, g.M, 0, g.K, nullptr, xr, tid);
-        load_stage<GUARD>(g.Y, g.ldy, j0, g.N, 0, g.K, g.s, yr, tid);
+        load_stage<true>(g.X, g.ldx, i0, g.M, 0, g.K, xr, tid);
+        load_stage<true>(g.Y, g.ldy, j0, g.N, 0, g.K, yr, tid);
         store_stage(Xs, xr, tid);
         store_stage(Ys, yr, tid);
     }
@@ -130,14 +128,59 @@ __device__ __forceinline__ void mainloop(const GemmArgs& g, int64_t i0, int64_t 
         const int buf = (int)(st & 1);
         const bool more = st + 1 < nstage;
         if (more) {
-            load_stage<GUARD>(g.X, g.ldx, i0, g.M, (st + 1) * BK, g.K, nullptr, xr, tid);
-            load_stage<GUARD>(g.Y, g.ldy, j0, g.N, (st + 1) * BK, g.K, g.s, yr, tid);
+            load_stage<true>(g.X, g.ldx, i0, g.M, (st + 1) * BK, g.K, xr, tid);
+            load_stage<true>(g.Y, g.ldy, j0, g.N, (st + 1) * BK, g.K, yr, tid);
         }
         compute_stage(Xs + buf * TILE_DOUBLES, Ys + buf * TILE_DOUBLES, wi, wj, lane, acc);
         if (more) {
             store_stage(Xs + (buf ^ 1) * TILE_DOUBLES, xr, tid);
             store_stage(Ys + (buf ^ 1) * TILE_DOUBLES, yr, tid);
         }
+        __syncthreads();
+    }
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// one stage of LDS-DMA: wave w moves tile rows w, w+4, w+8, w+12 of both operands (1 KiB each)
+__device__ __forceinline__ void dma_stage(const double* __restrict__ xp, const double* __restrict__ yp,
+                                          int64_t xstep, int64_t ystep, double* Xs, double* Ys,
+                                          int wave) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kr = r * 4 + wave;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(xp + r * xstep), (lds_ptr_t)(Xs + kr * LDT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(yp + r * ystep), (lds_ptr_t)(Ys + kr * LDT), 16, 0, 0);
+    }
+}
+
+// interior tiles: global -> LDS directly; the DMA of stage s+1 is in flight while stage s computes
+__device__ __forceinline__ void mainloop_dma(const GemmArgs& g, int64_t i0, int64_t j0, double* lds,
+                                             int wi, int wj, int lane, int wave,
+                                             double4_t (&acc)[4][4]) {
+    double* Xs = lds;
+    double* Ys = lds + 2 * TILE_DOUBLES;
+    const int64_t nstage = g.K / BK;
+    // lane's element of tile row `wave` of stage 0; rows r*4 + wave are 4*ld apart
+    const double* xp = g.X + (int64_t)wave * g.ldx + i0 + lane * 2;
+    const double* yp = g.Y + (int64_t)wave * g.ldy + j0 + lane * 2;
+    const int64_t xstep = 4 * g.ldx, ystep = 4 * g.ldy;
+    const int64_t xadv = (int64_t)BK * g.ldx, yadv = (int64_t)BK * g.ldy;
+    if (nstage > 0) {
+        dma_stage(xp, yp, xstep, ystep, Xs, Ys, wave);
+        xp += xadv;
+        yp += yadv;
+    }
+    __syncthreads();  // drains vmcnt (the DMA is an LDS write on the VM counter) and joins the waves
+    for (int64_t st = 0; st < nstage; ++st) {
+        const int buf = (int)(st & 1);
+        if (st + 1 < nstage) {
+            dma_stage(xp, yp, xstep, ystep, Xs + (buf ^ 1) * TILE_DOUBLES, Ys + (buf ^ 1) * TILE_DOUBLES, wave);
+            xp += xadv;
+            yp += yadv;
+        }
+        compute_stage(Xs + buf * TILE_DOUBLES, Ys + buf * TILE_DOUBLES, wi, wj, lane, acc);
         __syncthreads();
     }
 }
@@ -153,8 +196,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
     const int64_t i0 = (int64_t)(packed >> 16) * BM;
     const int64_t j0 = (int64_t)(packed & 0xFFFF) * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, lives in an SGPR
     const int wi = wave & 1, wj = wave >> 1;
+#ifdef MADQP_STAMPS
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     double4_t acc[4][4];
 #pragma unroll
@@ -164,10 +212,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
 
     const bool interior = ka.fast_ok && (i0 + BM <= g.M) && (j0 + BN <= g.N) && (g.K % BK == 0);
     if (interior)
-        mainloop<false>(g, i0, j0, lds, tid, wi, wj, lane, acc);
+        mainloop_dma(g, i0, j0, lds, wi, wj, lane, wave, acc);
     else
-        mainloop<true>(g, i0, j0, lds, tid, wi, wj, lane, acc);
+        mainloop_staged(g, i0, j0, lds, tid, wi, wj, lane, acc);
 
+#ifdef MADQP_STAMPS
+    if (ka.stamps && tid == 0) {
+        ka.stamps[2 * (size_t)bid] = __builtin_amdgcn_s_memtime() - st_t0;
+        ka.stamps[2 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#endif
     const int lo = lane & 15, hi = lane >> 4;
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
@@ -253,11 +307,42 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls) {
     ka.ntiles = it->second.n;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     ka.fast_ok = al16(a.X) && al16(a.Y) && (a.ldx % 2 == 0) && (a.ldy % 2 == 0);
+#ifdef MADQP_STAMPS
+    extern unsigned long long* madqp_stamp_buffer;
+    ka.stamps = madqp_stamp_buffer;
+#endif
     ProfScope ps(ctx, prof_cls);
     hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3(ka.ntiles), dim3(NTHREADS), 0, ctx->stream, ka);
     LAUNCH_CHECK(ctx);
     return MADQP_OK;
 }
+
+namespace {
+// Ys[k, :] = w[k] * B[k, :]  (one streaming pass, 16 n kdim bytes): keeps the per-k scaling out of
+// the MFMA loop, where every VALU instruction costs matrix-pipe cycles.
+__global__ __launch_bounds__(256) void scale_rows_kernel(int64_t n, int64_t kdim,
+                                                         const double* __restrict__ B, int64_t ldb,
+                                                         const double* __restrict__ w,
+                                                         double* __restrict__ out, int64_t ldo, int vec) {
+    const int64_t k = blockIdx.y;
+    const double wk = w[k];
+    const double* src = B + k * ldb;
+    double* dst = out + k * ldo;
+    if (vec) {
+        const int64_t pairs = n >> 1;
+        for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (int64_t)gridDim.x * 256) {
+            double2_t v = *reinterpret_cast<const double2_t*>(src + 2 * p);
+            v.x *= wk;
+            v.y *= wk;
+            *reinterpret_cast<double2_t*>(dst + 2 * p) = v;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1] * wk;
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+            dst[i] = src[i] * wk;
+    }
+}
+}  // namespace
 
 extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B,
                                        int64_t ldb, const double* w, const double* base,
@@ -271,7 +356,32 @@ extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, 
     g.ldx = ldb;
     g.Y = g.X;
     g.ldy = ldb;
-    g.s = w;
+    if (w && kdim > 0 && n > 0) {
+        // scaled copy of the operand in the context's scratch (grow-only)
+        const int64_t ldo = (n + 1) / 2 * 2;
+        const size_t bytes = (size_t)kdim * ldo * sizeof(double);
+        if (bytes > ctx->scaled_bytes) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_scaled) HIP_TRY(ctx, hipFree(ctx->d_scaled));
+            ctx->d_scaled = nullptr;
+            ctx->scaled_bytes = 0;
+            hipError_t e = hipMalloc(&ctx->d_scaled, bytes);
+            if (e != hipSuccess)
+                return madqp_fail(ctx, MADQP_ERR_ALLOC, "scaled operand hipMalloc(%zu): %s", bytes,
+                                  hipGetErrorString(e));
+            ctx->scaled_bytes = bytes;
+        }
+        const int vec = ((((uintptr_t)B) & 15) == 0) && (ldb % 2 == 0);
+        {
+            ProfScope ps(ctx, MADQP_PROF_VEC);
+            const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n / 2 + 255) / 256, 64));
+            hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, (unsigned)kdim), dim3(256), 0, ctx->stream, n,
+                               kdim, B, ldb, w, ctx->d_scaled, ldo, vec);
+            LAUNCH_CHECK(ctx);
+        }
+        g.Y = ctx->d_scaled;
+        g.ldy = ldo;
+    }
     g.C = C;
     g.ldc = ldc;
     g.Cin = base;

@@ -1,0 +1,67 @@
+// Diagnostic build of the GEMM core with per-workgroup clock stamps (never part of the product):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DMADQP_STAMPS -x hip tools/gemm_probe.cpp \
+//         madqp_jl_amd/csrc/{gemm_f64,ctx,gen}.hip -o tools/gemm_probe
+// Reports TFLOP/s, the in-kernel shader clock (s_memtime / s_memrealtime) and cycles per K-stage.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../include/madqp.h"
+unsigned long long* madqp_stamp_buffer = nullptr;
+
+static void run(madqp_ctx* ctx, int64_t n, int64_t k, bool scale, bool base) {
+    double *B, *w, *H, *C;
+    (void)hipMalloc(&B, sizeof(double) * n * k);
+    (void)hipMalloc(&w, sizeof(double) * k);
+    (void)hipMalloc(&H, sizeof(double) * n * n);
+    (void)hipMalloc(&C, sizeof(double) * n * n);
+    madqp_gen_normal(ctx, 123, 0, n * k, B);
+    madqp_gen_normal(ctx, 77, 0, k, w);
+    madqp_gen_normal(ctx, 99, 0, n * n, H);
+    const int64_t tiles = (n + 127) / 128;
+    const int64_t nt = tiles * (tiles + 1) / 2;
+    (void)hipMalloc(&madqp_stamp_buffer, nt * 16);
+    (void)hipMemset(madqp_stamp_buffer, 0, nt * 16);
+    madqp_syrk_assemble(ctx, n, k, B, n, scale ? w : nullptr, base ? H : nullptr, n, nullptr, C, n);
+    (void)hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, 0);
+    const int reps = 3;
+    for (int r = 0; r < reps; ++r)
+        madqp_syrk_assemble(ctx, n, k, B, n, scale ? w : nullptr, base ? H : nullptr, n, nullptr, C, n);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    std::vector<unsigned long long> h(nt * 2);
+    (void)hipMemcpy(h.data(), madqp_stamp_buffer, nt * 16, hipMemcpyDeviceToHost);
+    std::vector<double> ghz, cyc;
+    for (int64_t i = 0; i < nt; ++i)
+        if (h[2 * i + 1]) {
+            ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1);
+            cyc.push_back((double)h[2 * i] / ((double)k / 16.0));
+        }
+    std::sort(ghz.begin(), ghz.end());
+    std::sort(cyc.begin(), cyc.end());
+    const double flops = (double)k * n * n;  // lower triangle: 2 * k * n^2 / 2
+    printf("n=%lld k=%lld scale=%d base=%d: %.2f ms  %.2f TFLOP/s  clock median %.3f GHz (p5 %.3f p95 %.3f)  cycles/stage median %.0f\n",
+           (long long)n, (long long)k, scale, base, ms, flops / (ms * 1e-3) * 1e-12, ghz[ghz.size() / 2],
+           ghz[ghz.size() / 20], ghz[ghz.size() * 19 / 20], cyc[cyc.size() / 2]);
+    (void)hipFree(B); (void)hipFree(w); (void)hipFree(H); (void)hipFree(C); (void)hipFree(madqp_stamp_buffer);
+    madqp_stamp_buffer = nullptr;
+}
+
+int main() {
+    madqp_ctx* ctx;
+    if (madqp_ctx_create(0, nullptr, &ctx)) return 1;
+    run(ctx, 16384, 4096, false, false);
+    run(ctx, 16384, 4096, true, true);
+    run(ctx, 32768, 8192, true, true);
+    run(ctx, 4096, 4096, false, false);
+    madqp_ctx_destroy(ctx);
+    return 0;
+}
