@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of bench.py.
+# Usage: tools/profile_bench.sh <tag> [bench args...]; writes gpurun_out/prof_<tag>_*/
+set -u
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH_ARGS=("$@")
+run() { # name, rocprof args...
+  local name=$1; shift
+  timeout -k 10 600 rocprofv3 "$@" --output-format csv -d $OUT/prof_${TAG}_$name -- python3 $ROOT/bench.py --no-cpu-baseline "${BENCH_ARGS[@]}" > $OUT/prof_${TAG}_$name.log 2>&1
+  echo "$name rc=$?"; grep -o '"value": [0-9.e+-]*' $OUT/prof_${TAG}_$name.log | head -1
+}
+run stats --kernel-trace --stats
+run fetch --pmc FETCH_SIZE --kernel-trace
+run write --pmc WRITE_SIZE --kernel-trace
+run sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace
+run tcc --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace
+ls $OUT/prof_${TAG}_*/*/ 2>/dev/null | head -40
