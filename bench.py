@@ -78,8 +78,26 @@ def cpu_baseline(args, nx, m):
         measured_it_per_s_at_sample=iters / dt, sample_nx=sn, sample_m=sm)
 
 
-def main():
-    args = parse()
+def pmc_traffic(nx, m):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_summary.json, FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), if a
+    summary for this workload exists; PMC counters cannot be collected inside the timed run."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("config", {}).get("nx") != nx or d.get("config", {}).get("m") != m:
+                continue
+            g = d["gemm_tn_f64_kernel"]
+            return (g["hbm_read_GB_corrected"] + g["hbm_write_GB"]) * 1e9 / g["dispatches"], os.path.basename(f)
+        except Exception:
+            continue
+    return None, None
+
+
+def dist_setup(backend="nccl"):
+    """One process per GPU (torch.distributed.run): returns (world, rank, local_rank)."""
     import torch
     import torch.distributed as dist
 
@@ -88,14 +106,58 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return world, rank, local_rank
+
+
+def dist_barrier(world, cuda=True):
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.barrier()
+    if cuda:
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(elapsed, world, device):
+    """The job's time is the slowest rank's (contract: MAX over ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    if world <= 1:
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_value(world, steps, tmax):
+    """Whole-job throughput: every rank runs `steps` iterations of its own QP (weak scaling)."""
+    return world * steps / tmax
+
+
+def rank_seed(seed, rank):
+    """Independent instances: rank r solves the QP of seed + r."""
+    return seed + rank
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world, rank, local_rank = dist_setup("nccl")
 
     import madqp_jl_amd as M
 
     be = M.HipBackend(local_rank)
     nx, m = args.nx, args.m
-    dq = M.DeviceQP.synthetic(be, args.seed + rank, nx, m)
+    dq = M.DeviceQP.synthetic(be, rank_seed(args.seed, rank), nx, m)
     # options of scripts/benchmarks_cpu.jl:35-44 (kkt_system -> condensed, linear_solver -> HIP Cholesky)
     solver = M.MPCSolver(dq, be, max_iter=300, step_rule=M.AdaptiveStep(0.995),
                          regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12,
@@ -115,9 +177,7 @@ def main():
         solver.iteration_body()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        dist_barrier(world, cuda=True)
 
     for _ in range(args.warmup):
         step()
@@ -136,11 +196,7 @@ def main():
     be.prof_enable(())
     nfact = solver.kkt.n_factorizations - f0
 
-    tmax = elapsed
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=be.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tmax = float(t.item())
+    tmax = max_over_ranks(elapsed, world, be.device)
 
     if rank == 0:
         # dominant kernel: gemm_tn_f64_kernel (assembly + panel updates + panel x inverse block)
@@ -148,9 +204,10 @@ def main():
         gemm_launches = prof["syrk"][1] + prof["potrf_gemm"][1] + prof["potrf_trsm"][1]
         alg_flops = nfact * (m * nx * nx + nx ** 3 / 3.0)  # SYRK m nx^2 + POTRF nx^3/3
         achieved = alg_flops / (gemm_ms * 1e-3) * 1e-12 if gemm_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(nx, m)
         out = {
             "metric": "IPM iterations/sec (Mehrotra predictor-corrector, condensed KKT + Cholesky), dense QP fp64",
-            "value": world * args.steps / tmax,
+            "value": job_value(world, args.steps, tmax),
             "unit": "iterations/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -175,7 +232,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "gemm_tn_f64_kernel",
                 "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
                 "algorithmic_flops_per_launch": alg_flops / max(gemm_launches, 1),
                 "split": {k: {"ms": prof[k][0], "launches": prof[k][1]} for k in prof if prof[k][1]},

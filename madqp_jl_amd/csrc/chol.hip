@@ -4,10 +4,11 @@
 // dpotrf/dpotrs; reference call sites src/KKT/normalkkt.jl:99-101,196, src/linear_solver.jl:10-11).
 //
 // Factorisation, two levels of left-looking blocking so that >96 % of the flops run in wide GEMMs:
-//   for each outer panel J (NBO = 1024 columns)
-//     C[J0:n, J]  -= L[J0:n, 0:J0] * L[J, 0:J0]'            gemm core, N = 1024, K = J0   (MFMA)
-//     for each 128-column block jb inside J
-//       C[jb:n, jb] -= L[jb:n, J0:jb] * L[jb, J0:jb]'       gemm core, N = 128,  K <= 896 (MFMA)
+//   for each outer panel J (768..2048 columns, chosen to fill the last round of workgroups)
+//     C[J0:n, J]  -= L[J0:n, 0:J0] * L[J, 0:J0]'            gemm core, N = |J|,  K = J0   (MFMA)
+//     inside J, recursively: factor the first half, update the second half with it
+//       C[h:n, h:w] -= L[h:n, 0:h] * L[h:w, 0:h]'           gemm core, N = K = w/2        (MFMA)
+//     down to 128-column blocks jb:
 //       L_jj = chol(C_jj),  W_jj = L_jj^-1                   one workgroup, block resident in LDS
 //       L[jb+128:n, jb] = C[jb+128:n, jb] * W_jj'            gemm core, K = N = 128        (MFMA)
 // The inverse diagonal blocks W are kept (two images, 2 x n x 128 doubles) and turn the diagonal
@@ -317,6 +318,52 @@ static int32_t panel_update(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, i
     return madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_GEMM);
 }
 
+// One 128-column block whose entries already carry every update from the columns to its left:
+// factor the diagonal block (and invert it), then L[below, jb] = C[below, jb] * W_jj'.
+static int32_t factor_block(madqp_chol* s, double* A, int64_t lda, int64_t jb, int64_t w) {
+    madqp_ctx* ctx = s->ctx;
+    const int64_t n = s->n;
+    double* Wcm = s->winv + (jb / NB) * WBLK;
+    double* Wrm = Wcm + NB * NB;
+    {
+        ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
+        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, ctx->stream, A + jb + jb * lda, lda,
+                           (int)w, Wcm, Wrm, s->d_info, (int32_t)jb);
+        LAUNCH_CHECK(ctx);
+    }
+    if (jb + w < n) {
+        // out[i,j] = sum_k C[i,k] W(j,k); in place: a single tile column, every workgroup reads
+        // exactly the rows it writes and finishes reading (K = w, all stages) before its stores.
+        GemmArgs g{};
+        g.X = A + (jb + w) + jb * lda;
+        g.ldx = lda;
+        g.Y = Wcm;  // Y[j + k*NB] = W(j,k)
+        g.ldy = NB;
+        g.C = A + (jb + w) + jb * lda;
+        g.ldc = lda;
+        g.alpha = 1.0;
+        g.beta = 0.0;
+        g.M = n - jb - w;
+        g.N = w;
+        g.K = w;
+        return madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_TRSM);
+    }
+    return MADQP_OK;
+}
+
+// Recursive left-looking factorisation of the columns [j0, j0+w), which already carry the updates
+// of all columns < j0: factor the first half, apply it to the second half with ONE wide GEMM
+// (N = K = w/2), recurse.  Compared with a flat loop over 128-column blocks (N = 128, K up to
+// w - 128) this moves the in-panel flops into well-filled launches; only the leaves are narrow.
+static int32_t factor_range(madqp_chol* s, double* A, int64_t lda, int64_t j0, int64_t w) {
+    if (w <= NB) return factor_block(s, A, lda, j0, w);
+    const int64_t h = ((w + NB - 1) / NB + 1) / 2 * NB;  // first half, in whole blocks
+    int32_t r = factor_range(s, A, lda, j0, h);
+    if (r) return r;
+    if ((r = panel_update(s->ctx, A, lda, s->n, j0 + h, j0, w - h))) return r;
+    return factor_range(s, A, lda, j0 + h, w - h);
+}
+
 extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int32_t* info_host) {
     if (!s) return MADQP_ERR_ARG;
     madqp_ctx* ctx = s->ctx;
@@ -338,41 +385,8 @@ extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int3
             int32_t r = panel_update(ctx, A, lda, n, J0, 0, W);
             if (r) return r;
         }
-        for (int64_t jb = J0; jb < J0 + W; jb += NB) {
-            const int64_t w = std::min<int64_t>(NB, n - jb);
-            if (jb > J0) {
-                int32_t r = panel_update(ctx, A, lda, n, jb, J0, w);
-                if (r) return r;
-            }
-            double* Wcm = s->winv + (jb / NB) * WBLK;
-            double* Wrm = Wcm + NB * NB;
-            {
-                ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
-                hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, ctx->stream,
-                                   A + jb + jb * lda, lda, (int)w, Wcm, Wrm, s->d_info,
-                                   (int32_t)jb);
-                LAUNCH_CHECK(ctx);
-            }
-            if (jb + w < n) {
-                // L[jb+w:n, jb:jb+w] = C[jb+w:n, jb:jb+w] * W',  out[i,j] = sum_k C[i,k] W(j,k);
-                // in place: a single tile column, every workgroup reads exactly the rows it writes
-                // and finishes reading (K = w, all stages) before its epilogue stores.
-                GemmArgs g{};
-                g.X = A + (jb + w) + jb * lda;
-                g.ldx = lda;
-                g.Y = Wcm;  // Y[j + k*NB] = W(j,k)
-                g.ldy = NB;
-                g.C = A + (jb + w) + jb * lda;
-                g.ldc = lda;
-                g.alpha = 1.0;
-                g.beta = 0.0;
-                g.M = n - jb - w;
-                g.N = w;
-                g.K = w;
-                int32_t r = madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_TRSM);
-                if (r) return r;
-            }
-        }
+        int32_t r = factor_range(s, A, lda, J0, W);
+        if (r) return r;
     }
     int32_t info = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&info, s->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 outputs of tools/profile_bench.sh into profiles/<tag>_*.
+
+    python tools/summarize_pmc.py r01
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 64 B per
+128-B request of a wide coalesced stream, i.e. exactly half the bytes (MI355X_MICROARCH.md, HBM
+section), so it is doubled here; WRITE_SIZE is exact for 16-B-per-lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag = sys.argv[1]
+out = {}
+
+
+def rows(kind):
+    f = glob.glob(f"gpurun_out/prof_{tag}_{kind}/*/*_counter_collection.csv")
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def short(name):
+    for k in ("gemm_tn_f64_kernel", "potf2_inv_kernel", "gemv_n_wave", "gemv_n_block", "gemv_t_kernel",
+              "trsv_diag_fwd", "trsv_diag_bwd", "scale_rows_kernel"):
+        if k in name:
+            return k
+    return None
+
+
+per = collections.defaultdict(lambda: dict(dispatches=set(), ms=0.0, counters=collections.defaultdict(float)))
+largest = {}
+for kind in ("fetch", "write", "sq", "tcc"):
+    seen = set()
+    for r in rows(kind):
+        k = short(r["Kernel_Name"])
+        if not k:
+            continue
+        p = per[k]
+        p["counters"][r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (kind, r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key)
+            if kind == "fetch":
+                p["dispatches"].add(r["Dispatch_Id"])
+                p["ms"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+        if k == "gemm_tn_f64_kernel":
+            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+            cur = largest.setdefault(kind, dict(ms=0.0, id=None, counters={}))
+            if d > cur["ms"] and r["Dispatch_Id"] != cur["id"]:
+                cur.update(ms=d, id=r["Dispatch_Id"], counters={})
+            if r["Dispatch_Id"] == cur["id"]:
+                cur["counters"][r["Counter_Name"]] = float(r["Counter_Value"])
+
+for k, p in per.items():
+    c = dict(p["counters"])
+    e = dict(dispatches=len(p["dispatches"]), total_ms_under_pmc=round(p["ms"], 3), counters=c)
+    if "FETCH_SIZE" in c:
+        e["hbm_read_GB_corrected"] = c["FETCH_SIZE"] * 1024 * 2 / 1e9
+    if "WRITE_SIZE" in c:
+        e["hbm_write_GB"] = c["WRITE_SIZE"] * 1024 / 1e9
+    if "TCC_HIT_sum" in c:
+        e["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    out[k] = e
+big = {}
+for kind, v in largest.items():
+    big[kind] = dict(ms=v["ms"], **v["counters"])
+if big:
+    rd = big.get("fetch", {}).get("FETCH_SIZE", 0) * 1024 * 2
+    wr = big.get("write", {}).get("WRITE_SIZE", 0) * 1024
+    out["largest_gemm_dispatch (the assembly SYRK)"] = dict(
+        per_pass=big, hbm_read_bytes_corrected=rd, hbm_write_bytes=wr, traffic_bytes=rd + wr,
+        mfma_busy_fraction=(big.get("sq", {}).get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0)
+        / max(big.get("sq", {}).get("ms", 1) * 1e-3 * 2.385e9, 1))
+nx = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+m = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+out["config"] = dict(nx=nx, m=m, command=f"rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --nx {nx} --m {m}")
+json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+for f in glob.glob(f"gpurun_out/prof_{tag}_stats/*/*_kernel_stats.csv"):
+    shutil.copy(f, f"profiles/{tag}_bench50k_kernel_stats.csv")
+print(json.dumps(out, indent=1)[:3000])
