@@ -52,6 +52,14 @@ def cpu_baseline(args, nx, m):
     from oracle import mpc
     from oracle import qp as Q
 
+    # BLAS threads: the box's CPU share for one GPU is 16 cores (its affinity mask shows all of them)
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    try:
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(limits=cores)
+    except Exception:
+        pass
     sn = min(args.cpu_sample_nx, nx)
     sm = max(1, int(round(sn * m / nx)))
     qp = Q.synthetic_qp(args.seed, sn, sm)
@@ -69,10 +77,9 @@ def cpu_baseline(args, nx, m):
     dt = time.perf_counter() - t0
     flops = lambda a, b: b * a * a + a ** 3 / 3.0
     scale = flops(sn, sm) / flops(nx, m)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     return dict(
         value=(iters / dt) * scale, unit="IPM iterations/s", cores=cores, kind="port",
-        sample=(f"oracle/mpc.py (numpy+scipy LAPACK, all {cores} host threads) on the same synthetic "
+        sample=(f"oracle/mpc.py (numpy+scipy LAPACK, {cores} BLAS threads = the box's CPU share) on the same synthetic "
                 f"family at nx={sn}, m={sm}: {iters} iterations in {dt:.2f} s = {iters / dt:.3f} it/s, "
                 f"scaled by the flop ratio (m nx^2 + nx^3/3) {scale:.3e} to nx={nx}, m={m}"),
         measured_it_per_s_at_sample=iters / dt, sample_nx=sn, sample_m=sm)

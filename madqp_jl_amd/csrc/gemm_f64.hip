@@ -32,6 +32,7 @@
 // XCD and its L2) walks one contiguous chunk of the table: the 64 tiles resident on an XCD
 // share 8 X panels and 8 Y panels.
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 
 #include "common.h"
@@ -48,6 +49,7 @@ struct KArgs {
     const int32_t* table;
     int32_t ntiles;
     int32_t fast_ok;  // pointers / leading dimensions allow 16-byte loads
+    int32_t xcd_remap;
 #ifdef MADQP_STAMPS
     unsigned long long* stamps;  // diagnostic build only (tools/gemm_probe): per-workgroup clocks
 #endif
@@ -141,47 +143,132 @@ __device__ __forceinline__ void mainloop_staged(const GemmArgs& g, int64_t i0, i
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-// one stage of LDS-DMA: wave w moves tile rows w, w+4, w+8, w+12 of both operands (1 KiB each)
-__device__ __forceinline__ void dma_stage(const double* __restrict__ xp, const double* __restrict__ yp,
-                                          int64_t xstep, int64_t ystep, double* Xs, double* Ys,
-                                          int wave) {
+// ---- interior-tile main loop: no vector-ALU instruction between the MFMAs -----------------
+// Measured on gfx950 (tools/mfma_probe.hip): one VALU instruction per fp64 MFMA costs ~13 cycles
+// of matrix pipe, LDS reads cost none.  So the steady-state loop uses
+//   * ds_read_b64 with 16-bit immediate offsets from two per-lane base registers (no address adds),
+//   * global_load_lds_dwordx4 in the saddr form: scalar row pointer + constant per-lane offset,
+//     LDS destination through M0 -- all address arithmetic is on the scalar unit,
+//   * counted s_waitcnt written by hand (the compiler does not see inline-asm memory operations).
+constexpr int ROW_BYTES = LDT * 8;          // 1152
+constexpr int TILE_BYTES = BK * ROW_BYTES;  // 18432
+constexpr int Y_BYTES = 2 * TILE_BYTES;     // Y tiles start after the two X buffers
+
+template <int OFF>
+__device__ __forceinline__ double lds_read(unsigned base) {
+    double d;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(base), "n"(OFF));
+    return d;
+}
+
+// fragments of k-step KK (4 k's) of the buffer the bases point into: a <- Y tile, b <- X tile
+template <int KK>
+__device__ __forceinline__ void read_frags(unsigned vx, unsigned vy, double (&a)[4], double (&b)[4]) {
+    constexpr int o = KK * 4 * ROW_BYTES;
+    a[0] = lds_read<o + 0 * 128>(vy);
+    a[1] = lds_read<o + 1 * 128>(vy);
+    a[2] = lds_read<o + 2 * 128>(vy);
+    a[3] = lds_read<o + 3 * 128>(vy);
+    b[0] = lds_read<o + 0 * 128>(vx);
+    b[1] = lds_read<o + 1 * 128>(vx);
+    b[2] = lds_read<o + 2 * 128>(vx);
+    b[3] = lds_read<o + 3 * 128>(vx);
+}
+
+// wait until at most N LDS reads are outstanding; the "+v" ties make the fragments depend on it
+template <int N>
+__device__ __forceinline__ void lds_wait(double (&a)[4], double (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(N));
+}
+
+__device__ __forceinline__ void mfma16(const double (&a)[4], const double (&b)[4], double4_t (&acc)[4][4]) {
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tj], b[ti], acc[ti][tj], 0, 0, 0);
+}
+
+__device__ __forceinline__ void compute_stage_asm(unsigned vx, unsigned vy, double4_t (&acc)[4][4]) {
+    double a0[4], b0[4], a1[4], b1[4];
+    read_frags<0>(vx, vy, a0, b0);
+    read_frags<1>(vx, vy, a1, b1);
+    lds_wait<8>(a0, b0);
+    mfma16(a0, b0, acc);
+    read_frags<2>(vx, vy, a0, b0);
+    lds_wait<8>(a1, b1);
+    mfma16(a1, b1, acc);
+    read_frags<3>(vx, vy, a1, b1);
+    lds_wait<8>(a0, b0);
+    mfma16(a0, b0, acc);
+    lds_wait<0>(a1, b1);
+    mfma16(a1, b1, acc);
+}
+
+// one LDS-DMA: 64 lanes x 16 B = one 1 KiB tile row; global address = scalar row pointer + lane*16
+__device__ __forceinline__ void dma_row(const double* row, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(row)
+                 : "memory");
+}
+
+// one stage of both operands into the buffer at scalar LDS address lds0 (X) / lds0 + Y_BYTES (Y):
+// wave w moves tile rows w, w+4, w+8, w+12
+__device__ __forceinline__ void dma_stage_asm(const double* xrow, const double* yrow, int64_t xstep,
+                                              int64_t ystep, unsigned lds0, unsigned voff) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int kr = r * 4 + wave;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(xp + r * xstep), (lds_ptr_t)(Xs + kr * LDT), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(yp + r * ystep), (lds_ptr_t)(Ys + kr * LDT), 16, 0, 0);
+        dma_row(xrow + r * xstep, lds0 + r * 4 * ROW_BYTES, voff);
+        dma_row(yrow + r * ystep, lds0 + Y_BYTES + r * 4 * ROW_BYTES, voff);
     }
+}
+
+__device__ __forceinline__ void dma_join() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 }
 
 // interior tiles: global -> LDS directly; the DMA of stage s+1 is in flight while stage s computes
 __device__ __forceinline__ void mainloop_dma(const GemmArgs& g, int64_t i0, int64_t j0, double* lds,
                                              int wi, int wj, int lane, int wave,
                                              double4_t (&acc)[4][4]) {
-    double* Xs = lds;
-    double* Ys = lds + 2 * TILE_DOUBLES;
-    const int64_t nstage = g.K / BK;
-    // lane's element of tile row `wave` of stage 0; rows r*4 + wave are 4*ld apart
-    const double* xp = g.X + (int64_t)wave * g.ldx + i0 + lane * 2;
-    const double* yp = g.Y + (int64_t)wave * g.ldy + j0 + lane * 2;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    const int nstage = __builtin_amdgcn_readfirstlane((int)(g.K / BK));  // scalar loop bound
+    // scalar pointers to tile row `wave` of the current stage; rows r*4 + wave are 4*ld apart
+    const double* xrow = g.X + (int64_t)wave * g.ldx + i0;
+    const double* yrow = g.Y + (int64_t)wave * g.ldy + j0;
     const int64_t xstep = 4 * g.ldx, ystep = 4 * g.ldy;
     const int64_t xadv = (int64_t)BK * g.ldx, yadv = (int64_t)BK * g.ldy;
+    const unsigned lds0 = lds_base + (unsigned)wave * ROW_BYTES;  // this wave's first row (scalar)
+    const unsigned voff = (unsigned)lane * 16;
+    // per-lane fragment bases: element (k = lane>>4, index = lane&15) of the wave's 64-wide strip
+    const unsigned rb = (unsigned)((lane >> 4) * ROW_BYTES + (lane & 15) * 8);
+    unsigned vx = lds_base + rb + (unsigned)wi * 512;
+    unsigned vy = lds_base + rb + (unsigned)wj * 512 + Y_BYTES;
     if (nstage > 0) {
-        dma_stage(xp, yp, xstep, ystep, Xs, Ys, wave);
-        xp += xadv;
-        yp += yadv;
+        dma_stage_asm(xrow, yrow, xstep, ystep, lds0, voff);
+        xrow += xadv;
+        yrow += yadv;
     }
-    __syncthreads();  // drains vmcnt (the DMA is an LDS write on the VM counter) and joins the waves
-    for (int64_t st = 0; st < nstage; ++st) {
-        const int buf = (int)(st & 1);
+    dma_join();
+    int toggle = TILE_BYTES;  // scalar: +TILE_BYTES, -TILE_BYTES, ... (buffer of the NEXT stage)
+    unsigned fill = lds0 + TILE_BYTES;
+    for (int st = 0; st < nstage; ++st) {
         if (st + 1 < nstage) {
-            dma_stage(xp, yp, xstep, ystep, Xs + (buf ^ 1) * TILE_DOUBLES, Ys + (buf ^ 1) * TILE_DOUBLES, wave);
-            xp += xadv;
-            yp += yadv;
+            dma_stage_asm(xrow, yrow, xstep, ystep, fill, voff);
+            xrow += xadv;
+            yrow += yadv;
         }
-        compute_stage(Xs + buf * TILE_DOUBLES, Ys + buf * TILE_DOUBLES, wi, wj, lane, acc);
-        __syncthreads();
+        compute_stage_asm(vx, vy, acc);
+        dma_join();
+        vx += toggle;  // the two VALU instructions of a stage
+        vy += toggle;
+        fill -= toggle;
+        toggle = -toggle;
     }
 }
 
@@ -191,7 +278,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
     // XCD-contiguous remap of the workgroup id (bijective for any grid size)
     const int bid = blockIdx.x, T = ka.ntiles;
     const int xcd = bid & 7, q = T >> 3, r = T & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int t = ka.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
     const int32_t packed = ka.table[t];
     const int64_t i0 = (int64_t)(packed >> 16) * BM;
     const int64_t j0 = (int64_t)(packed & 0xFFFF) * BN;
@@ -276,19 +363,38 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls) {
     const int64_t tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     ARG_TRY(ctx, tiles_m < 65536 && tiles_n < 32768);
     // diag_off in tile units must be exact for the tile-skip test used when building the table
-    TableKey key{tiles_m, tiles_n, a.lower_only ? 1 : 0, a.lower_only ? a.diag_off : 0};
+    TableKey key{tiles_m, tiles_n,
+                 (a.lower_only ? 1 : 0) | ((a.M % BM) != 0 ? 2 : 0) | ((a.N % BN) != 0 ? 4 : 0),
+                 a.lower_only ? a.diag_off : 0};
     auto& cache = table_cache()[ctx];
     auto it = cache.find(key);
     if (it == cache.end()) {
         std::vector<int32_t> tab;
         tab.reserve((size_t)tiles_m * tiles_n);
-        constexpr int64_t P = 8;  // patch of P x P tiles
-        for (int64_t pm = 0; pm < tiles_m; pm += P)
-            for (int64_t pn = 0; pn < tiles_n; pn += P)
-                for (int64_t tn = pn; tn < pn + P && tn < tiles_n; ++tn)
-                    for (int64_t tm = pm; tm < pm + P && tm < tiles_m; ++tm) {
-                        // tile holds an element with i + diag_off >= j ?
-                        if (a.lower_only && (tm * BM + BM - 1 + a.diag_off < tn * BN)) continue;
+        // patch of PM x PN tiles (tuning knobs for experiments: MADQP_GEMM_PATCH_M / _N)
+        static const int64_t PM = getenv("MADQP_GEMM_PATCH_M") ? atoi(getenv("MADQP_GEMM_PATCH_M")) : 8;
+        static const int64_t PN = getenv("MADQP_GEMM_PATCH_N") ? atoi(getenv("MADQP_GEMM_PATCH_N")) : 8;
+        // Edge tiles (partial last tile row / column, or K not a multiple of 16) run the slower
+        // register-staged loop: they go FIRST so that they overlap with the bulk instead of forming
+        // the tail of the launch.
+        const bool m_edge = (a.M % BM) != 0, n_edge = (a.N % BN) != 0;
+        auto active = [&](int64_t tm, int64_t tn) {
+            return !(a.lower_only && (tm * BM + BM - 1 + a.diag_off < tn * BN));
+        };
+        auto is_edge = [&](int64_t tm, int64_t tn) {
+            return (m_edge && tm == tiles_m - 1) || (n_edge && tn == tiles_n - 1);
+        };
+        if (m_edge)
+            for (int64_t tn = 0; tn < tiles_n; ++tn)
+                if (active(tiles_m - 1, tn)) tab.push_back((int32_t)(((tiles_m - 1) << 16) | tn));
+        if (n_edge)
+            for (int64_t tm = 0; tm < tiles_m - (m_edge ? 1 : 0); ++tm)
+                if (active(tm, tiles_n - 1)) tab.push_back((int32_t)((tm << 16) | (tiles_n - 1)));
+        for (int64_t pm = 0; pm < tiles_m; pm += PM)
+            for (int64_t pn = 0; pn < tiles_n; pn += PN)
+                for (int64_t tn = pn; tn < pn + PN && tn < tiles_n; ++tn)
+                    for (int64_t tm = pm; tm < pm + PM && tm < tiles_m; ++tm) {
+                        if (!active(tm, tn) || is_edge(tm, tn)) continue;
                         tab.push_back((int32_t)((tm << 16) | tn));
                     }
         TableVal v{nullptr, (int32_t)tab.size()};
@@ -305,6 +411,8 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls) {
     ka.g = a;
     ka.table = it->second.d;
     ka.ntiles = it->second.n;
+    static const int xcd_remap = getenv("MADQP_GEMM_XCD") ? atoi(getenv("MADQP_GEMM_XCD")) : 1;
+    ka.xcd_remap = xcd_remap;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     ka.fast_ok = al16(a.X) && al16(a.Y) && (a.ldx % 2 == 0) && (a.ldy % 2 == 0);
 #ifdef MADQP_STAMPS

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../include/madqp.h"
+#include "../madqp_jl_amd/csrc/common.h"
 unsigned long long* madqp_stamp_buffer = nullptr;
 
 static void run(madqp_ctx* ctx, int64_t n, int64_t k, bool scale, bool base) {
@@ -55,13 +56,61 @@ static void run(madqp_ctx* ctx, int64_t n, int64_t k, bool scale, bool base) {
     madqp_stamp_buffer = nullptr;
 }
 
+// left-looking panel update of chol.hip on an n x n column-major matrix: C[J0:n, J0:J0+W] -= L[J0:n,0:J0] L[J0:J0+W,0:J0]'
+static void run_panel(madqp_ctx* ctx, int64_t n, int64_t J0, int64_t W, int variant) {
+    double* A;
+    (void)hipMalloc(&A, sizeof(double) * n * n);
+    madqp_gen_normal(ctx, 5, 0, n * n, A);
+    GemmArgs g{};
+    g.X = A + J0; g.ldx = n; g.Y = A + J0; g.ldy = n;
+    g.C = A + J0 + J0 * n; g.ldc = n; g.Cin = (variant & 1) ? nullptr : g.C; g.ldcin = n;
+    g.alpha = -1.0; g.beta = 1.0; g.M = n - J0; g.N = W; g.K = J0; g.diag_off = 0; g.lower_only = (variant & 2) ? 0 : 1;
+    const int64_t tm = (g.M + 127) / 128, tn = (g.N + 127) / 128;
+    int64_t nt = tm * tn;
+    (void)hipMalloc(&madqp_stamp_buffer, nt * 16);
+    (void)hipMemset(madqp_stamp_buffer, 0, nt * 16);
+    madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_GEMM);
+    (void)hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, 0);
+    const int reps = 3;
+    for (int r = 0; r < reps; ++r) madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_GEMM);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    int64_t active = g.lower_only ? tm * tn - tn * (tn - 1) / 2 : tm * tn;
+    std::vector<unsigned long long> h(nt * 2);
+    (void)hipMemcpy(h.data(), madqp_stamp_buffer, nt * 16, hipMemcpyDeviceToHost);
+    std::vector<double> cyc;
+    for (int64_t i = 0; i < nt; ++i) if (h[2 * i + 1]) cyc.push_back((double)h[2 * i] / ((double)g.K / 16.0));
+    std::sort(cyc.begin(), cyc.end());
+    printf("panel n=%lld J0=%lld W=%lld variant=%d: tiles %lld (%.2f rounds) %.2f ms %.2f TFLOP/s cycles/stage median %.0f p90 %.0f\n",
+           (long long)n, (long long)J0, (long long)W, variant, (long long)active, active / 512.0, ms,
+           2.0 * active * 128 * 128 * g.K / (ms * 1e-3) * 1e-12, cyc.size() ? cyc[cyc.size() / 2] : 0.0,
+           cyc.size() ? cyc[cyc.size() * 9 / 10] : 0.0);
+    (void)hipFree(A); (void)hipFree(madqp_stamp_buffer); madqp_stamp_buffer = nullptr;
+}
+
 int main() {
     madqp_ctx* ctx;
     if (madqp_ctx_create(0, nullptr, &ctx)) return 1;
-    run(ctx, 16384, 4096, false, false);
-    run(ctx, 16384, 4096, true, true);
-    run(ctx, 32768, 8192, true, true);
-    run(ctx, 4096, 4096, false, false);
+    if (getenv("PROBE_PANEL")) {
+        run_panel(ctx, 40960, 20480, 2048, 0);
+        run_panel(ctx, 40960, 20480, 2048, 1);
+        run_panel(ctx, 40960, 20480, 2048, 2);
+        run_panel(ctx, 40960, 20480, 2048, 3);
+        run_panel(ctx, 40960, 32768, 1024, 0);
+        run_panel(ctx, 40960, 8192, 2048, 0);
+        run(ctx, 24576, 20480, true, true);
+    } else if (getenv("PROBE_ONE")) {
+        run(ctx, 24576, 8192, true, true);
+    } else {
+        run(ctx, 16384, 4096, false, false);
+        run(ctx, 16384, 4096, true, true);
+        run(ctx, 32768, 8192, true, true);
+        run(ctx, 4096, 4096, false, false);
+    }
     madqp_ctx_destroy(ctx);
     return 0;
 }

@@ -7,9 +7,18 @@
 #include <vector>
 #include <algorithm>
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
-template <int NACC, int WPS, int FILL>
+// KIND: 0 = v_fma_f32, 1 = ds_read_b64 (imm offset), 2 = s_add_u32, 3 = ds_read2_b64, 4 = v_add_u32
+template <int NACC, int WPS, int FILL, int KIND = 0>
 __global__ __launch_bounds__(256, WPS) void probe(int iters, unsigned long long* out, double seed) {
+    __shared__ double lds[4096];
+    lds[threadIdx.x] = seed;
+    __syncthreads();
+    unsigned laddr = (threadIdx.x & 63) * 8;
+    double dl0 = 0, dl1 = 0;
+    double2_t dl2 = {0, 0};
+    unsigned sc = 0, va = threadIdx.x;
     double4_t acc[NACC];
     for (int i = 0; i < NACC; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
     double a = seed + threadIdx.x * 1.0e-3, b = 1.0 - threadIdx.x * 3.0e-3;
@@ -21,10 +30,18 @@ __global__ __launch_bounds__(256, WPS) void probe(int iters, unsigned long long*
         for (int i = 0; i < NACC; ++i) {
             asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
 #pragma unroll
-            for (int q = 0; q < FILL; ++q) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f));
+            for (int q = 0; q < FILL; ++q) {
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f));
+                if (KIND == 1) asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(dl0) : "v"(laddr));
+                if (KIND == 2) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc));
+                if (KIND == 3) asm volatile("ds_read2_b64 %0, %1 offset0:4 offset1:20" : "=v"(dl2) : "v"(laddr));
+                if (KIND == 4) asm volatile("v_add_u32 %0, 4, %0" : "+v"(va));
+            }
+            if (KIND == 1 || KIND == 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
         }
     }
-    double s = f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double s = f + dl0 + dl1 + dl2.x + dl2.y + (double)sc + (double)va;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
@@ -36,7 +53,7 @@ __global__ __launch_bounds__(256, WPS) void probe(int iters, unsigned long long*
     if (s == 1234.5) out[0] = 0;
 }
 
-template <int NACC, int WPS, int FILL>
+template <int NACC, int WPS, int FILL, int KIND = 0>
 void run(int iters) {
     const int blocks = 256 * WPS;
     unsigned long long* d;
@@ -45,9 +62,9 @@ void run(int iters) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((probe<NACC, WPS, FILL>), dim3(blocks), dim3(256), 0, 0, 100, d, 0.37);
+    hipLaunchKernelGGL((probe<NACC, WPS, FILL, KIND>), dim3(blocks), dim3(256), 0, 0, 100, d, 0.37);
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((probe<NACC, WPS, FILL>), dim3(blocks), dim3(256), 0, 0, iters, d, 0.37);
+    hipLaunchKernelGGL((probe<NACC, WPS, FILL, KIND>), dim3(blocks), dim3(256), 0, 0, iters, d, 0.37);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     float ms;
@@ -62,8 +79,8 @@ void run(int iters) {
     std::sort(cyc.begin(), cyc.end());
     std::sort(ghz.begin(), ghz.end());
     const double flops = (double)nw * iters * NACC * 2048.0;
-    printf("NACC=%2d waves/SIMD=%d fill=%d: %8.3f ms %6.2f TFLOP/s  cycles/MFMA/wave %6.1f (per SIMD %5.1f)  clock %.3f GHz\n",
-           NACC, WPS, FILL, ms, flops / (ms * 1e-3) * 1e-12, cyc[nw / 2], cyc[nw / 2] / WPS, ghz[nw / 2]);
+    printf("NACC=%2d waves/SIMD=%d fill=%d kind=%d: %8.3f ms %6.2f TFLOP/s  cycles/MFMA/wave %6.1f (per SIMD %5.1f)  clock %.3f GHz\n",
+           NACC, WPS, FILL, KIND, ms, flops / (ms * 1e-3) * 1e-12, cyc[nw / 2], cyc[nw / 2] / WPS, ghz[nw / 2]);
     (void)hipFree(d);
 }
 
@@ -81,5 +98,18 @@ int main() {
     run<16, 1, 4>(25000);
     run<16, 1, 8>(25000);
     run<16, 2, 4>(25000);
+    run<16, 1, 1, 0>(25000);
+    run<16, 2, 1, 0>(25000);
+    run<16, 1, 1, 1>(25000);
+    run<16, 1, 2, 1>(25000);
+    run<16, 2, 1, 1>(25000);
+    run<16, 2, 2, 1>(25000);
+    run<16, 1, 1, 3>(25000);
+    run<16, 2, 1, 3>(25000);
+    run<16, 1, 2, 2>(25000);
+    run<16, 1, 8, 2>(25000);
+    run<16, 2, 4, 2>(25000);
+    run<16, 1, 1, 4>(25000);
+    run<16, 2, 1, 4>(25000);
     return 0;
 }

@@ -18,4 +18,5 @@ run fetch --pmc FETCH_SIZE --kernel-trace
 run write --pmc WRITE_SIZE --kernel-trace
 run sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace
 run tcc --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace
+run sq2 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM --kernel-trace
 ls $OUT/prof_${TAG}_*/*/ 2>/dev/null | head -40
