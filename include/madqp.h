@@ -213,6 +213,13 @@ int32_t madqp_sp_check(madqp_ctx* ctx, const madqp_state* st, int32_t* ok_host);
 int32_t madqp_kkt_create(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
                          const int64_t* ind_ineq_host, const double* H, int64_t ldh,
                          const double* A, int64_t lda, madqp_kkt** out);
+/* The reference's own formulation, NormalKKTSystem (src/KKT/normalkkt.jl:29-126): normal equations
+ * S = A Sigma_x^-1 A' + diag(Sigma_s^-1) (m x m), LP only (:45-48), equality rows need no
+ * regularization.  At: nx x m with row k (variable k) contiguous = a Julia m x nx `Matrix` A as is;
+ * borrowed.  The object answers the same madqp_kkt_* calls below. */
+int32_t madqp_kkt_create_normal(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
+                                const int64_t* ind_ineq_host, const double* At, int64_t ldat,
+                                madqp_kkt** out);
 int32_t madqp_kkt_destroy(madqp_kkt* kkt);
 /* MadNLP.build_kkt! (src/KKT/normalkkt.jl:166-180): Theta from pr_diag/du_diag, then the SYRK */
 int32_t madqp_kkt_build(madqp_kkt* kkt, const madqp_state* st);

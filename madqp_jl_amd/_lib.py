@@ -89,6 +89,7 @@ _SIGNATURES = {
     "madqp_sp_project": [vp, pstate, f64],
     "madqp_sp_check": [vp, pstate, pi32],
     "madqp_kkt_create": [vp, i64, i64, i64, pi64, vp, i64, vp, i64, C.POINTER(vp)],
+    "madqp_kkt_create_normal": [vp, i64, i64, i64, pi64, vp, i64, C.POINTER(vp)],
     "madqp_kkt_destroy": [vp],
     "madqp_kkt_build": [vp, pstate],
     "madqp_kkt_factorize": [vp, pi32],

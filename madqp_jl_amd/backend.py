@@ -273,6 +273,13 @@ class HipBackend:
         self._ck(self.lib.madqp_kkt_create(self.ctx, nx, m, ns, arr, ptr(H), ldh, ptr(A), lda, C.byref(h)))
         return h
 
+    def kkt_create_normal(self, nx, m, ind_ineq, At, ldat):
+        ns = len(ind_ineq)
+        arr = (C.c_int64 * max(ns, 1))(*[int(i) for i in ind_ineq])
+        h = C.c_void_p()
+        self._ck(self.lib.madqp_kkt_create_normal(self.ctx, nx, m, ns, arr, ptr(At), ldat, C.byref(h)))
+        return h
+
     def kkt_destroy(self, h):
         self.lib.madqp_kkt_destroy(h)
 

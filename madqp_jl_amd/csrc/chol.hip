@@ -213,29 +213,33 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
     }
 }
 
-// forward diagonal step:  b_j <- W_jj b_j       (y[r] = sum_{c<=r} W(r,c) b[c]), lanes over r
-__global__ __launch_bounds__(128) void trsv_diag_fwd_kernel(const double* __restrict__ Wcm,
-                                                            double* __restrict__ b, int nb) {
-    __shared__ double bs[NB];
-    const int r = threadIdx.x;
-    bs[r] = (r < nb) ? b[r] : 0.0;
+// Diagonal step of a triangular sweep as a 128 x 128 mat-vec with the inverse block:
+//   forward :  b_j <- W_jj  b_j          img = Wcm  (img[i + j*NB] = W(i,j))
+//   backward:  b_j <- W_jj' (b_j - t)    img = Wrm  (img[i + j*NB] = W(j,i))
+// 1024 threads: 8 column slices of 16 per output row, 16 independent coalesced loads per thread
+// (the kernel sits on the critical path of the sweep: latency, not bandwidth).
+__global__ __launch_bounds__(1024) void trsv_diag_kernel(const double* __restrict__ img,
+                                                         double* __restrict__ b,
+                                                         const double* __restrict__ t, int nb) {
+    __shared__ double vs[NB];
+    __shared__ double part[8][NB];
+    const int i = threadIdx.x & (NB - 1), p = threadIdx.x >> 7;
+    if (threadIdx.x < NB) vs[i] = (i < nb) ? (b[i] - (t ? t[i] : 0.0)) : 0.0;
     __syncthreads();
     double acc = 0.0;
-    for (int c = 0; c < nb; ++c) acc += Wcm[r + c * NB] * bs[c];  // W is zero above the diagonal
-    if (r < nb) b[r] = acc;
-}
-
-// backward diagonal step:  b_j <- W_jj' (b_j - t)   (y[c] = sum_{r>=c} W(r,c) (b[r]-t[r])), lanes over c
-__global__ __launch_bounds__(128) void trsv_diag_bwd_kernel(const double* __restrict__ Wrm,
-                                                            double* __restrict__ b,
-                                                            const double* __restrict__ t, int nb) {
-    __shared__ double bs[NB];
-    const int c = threadIdx.x;
-    bs[c] = (c < nb) ? (b[c] - (t ? t[c] : 0.0)) : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = p * 16 + q;
+        acc += img[i + j * NB] * vs[j];
+    }
+    part[p][i] = acc;
     __syncthreads();
-    double acc = 0.0;
-    for (int r = 0; r < nb; ++r) acc += Wrm[c + r * NB] * bs[r];
-    if (c < nb) b[c] = acc;
+    if (threadIdx.x < NB && i < nb) {
+        double s = part[0][i];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s += part[q][i];
+        b[i] = s;
+    }
 }
 }  // namespace
 
@@ -409,8 +413,8 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
         const double* Wcm = s->winv + (jb / NB) * WBLK;
         {
             ProfScope ps(ctx, MADQP_PROF_TRSV);
-            hipLaunchKernelGGL(trsv_diag_fwd_kernel, dim3(1), dim3(NB), 0, ctx->stream, Wcm,
-                               rhs + jb, (int)w);
+            hipLaunchKernelGGL(trsv_diag_kernel, dim3(1), dim3(1024), 0, ctx->stream, Wcm, rhs + jb,
+                               (const double*)nullptr, (int)w);
             LAUNCH_CHECK(ctx);
         }
         const int64_t below = n - jb - w;
@@ -436,7 +440,7 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
             t = s->tmp;
         }
         ProfScope ps(ctx, MADQP_PROF_TRSV);
-        hipLaunchKernelGGL(trsv_diag_bwd_kernel, dim3(1), dim3(NB), 0, ctx->stream, Wrm, rhs + jb,
+        hipLaunchKernelGGL(trsv_diag_kernel, dim3(1), dim3(1024), 0, ctx->stream, Wrm, rhs + jb,
                            t, (int)w);
         LAUNCH_CHECK(ctx);
     }

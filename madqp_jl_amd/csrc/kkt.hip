@@ -7,6 +7,12 @@
 //   equality   row i             :  Theta_i = -1 / dc_i              (requires dc_i < 0)
 //   rhs_x = r1_x + A' Theta (r2 + r1_s / S),   K dx = rhs_x,
 //   dy = Theta (A dx - r2 - r1_s / S),          ds = (r1_s + dy) / S
+//
+// The same object also provides the reference's own formulation (mode NORMAL): the normal
+// equations  S = A_full Sigma^-1 A_full' = A Sigma_x^-1 A' + diag(Sigma_s^-1)  (m x m) of
+// src/KKT/normalkkt.jl:166-205, LP only as there (:45-48), dual regularization not added to the
+// matrix.  It needs A' with row k (a variable) contiguous, which is again the
+// k-major layout the GEMM core consumes; equality rows need no regularization in this form.
 #include <algorithm>
 
 #include "common.h"
@@ -14,13 +20,19 @@
 #define TPB 256
 #define MADQP_MAX_BLOCKS 1024
 
+enum { KKT_CONDENSED = 0, KKT_NORMAL = 1 };
+
 struct madqp_kkt {
     madqp_ctx* ctx;
+    int mode;
     int64_t nx, m, ns;
     const double* H;
     int64_t ldh;
-    const double* A;
+    const double* A;  // m x nx, row k = constraint k contiguous (condensed mode)
     int64_t lda;
+    const double* At;  // nx x m, row k = variable k contiguous (normal mode)
+    int64_t ldat;
+    double *dn, *tn;  // normal mode: 1/Sigma (n) and an n-vector of scratch
     int64_t* d_ind_ineq;  // ns
     int64_t* d_slot;      // m: slack slot of a row, -1 for an equality row
     double* K;
@@ -165,6 +177,46 @@ __global__ __launch_bounds__(TPB) void eval_cons_kernel(int64_t m, const int64_t
         c[i] = a - rhs[i];
     }
 }
+
+// ---- normal-equations mode (src/KKT/normalkkt.jl) ----
+// D = 1 / Sigma (normalkkt.jl:177) for all n entries
+__global__ __launch_bounds__(TPB) void recip_kernel(int64_t n, const double* __restrict__ pr_diag,
+                                                    double* __restrict__ d) {
+    GRID_STRIDE(i, n) d[i] = 1.0 / pr_diag[i];
+}
+// diagonal contribution of the slack columns (-1 entries): D_s on inequality rows, 0 on equality rows
+__global__ __launch_bounds__(TPB) void slack_diag_kernel(int64_t m, int64_t nx,
+                                                         const int64_t* __restrict__ slot,
+                                                         const double* __restrict__ d,
+                                                         double* __restrict__ out) {
+    GRID_STRIDE(i, m) {
+        const int64_t k = slot[i];
+        out[i] = (k >= 0) ? d[nx + k] : 0.0;
+    }
+}
+// r1 = wx / Sigma (normalkkt.jl:192)
+__global__ __launch_bounds__(TPB) void div_kernel(int64_t n, const double* __restrict__ a,
+                                                  const double* __restrict__ b, double* __restrict__ out) {
+    GRID_STRIDE(i, n) out[i] = a[i] / b[i];
+}
+// r2_i = (u_i - r1_s[slot]) - wy_i   (A_full r1 - r2, normalkkt.jl:193-194)
+__global__ __launch_bounds__(TPB) void normal_rhs_kernel(int64_t m, const int64_t* __restrict__ slot,
+                                                         const double* __restrict__ u,
+                                                         const double* __restrict__ r1s,
+                                                         const double* wy, double* out) {
+    GRID_STRIDE(i, m) {  // out may alias wy (elementwise)
+        const int64_t k = slot[i];
+        double a = u[i];
+        if (k >= 0) a -= r1s[k];
+        out[i] = a - wy[i];
+    }
+}
+// wx = (wx - t) / Sigma   (normalkkt.jl:199-201)
+__global__ __launch_bounds__(TPB) void normal_back_kernel(int64_t n, const double* __restrict__ t,
+                                                          const double* __restrict__ pr_diag,
+                                                          double* __restrict__ wx) {
+    GRID_STRIDE(i, n) wx[i] = (wx[i] - t[i]) / pr_diag[i];
+}
 }  // namespace
 
 #define KLAUNCH(kern, len, ...)                                                                 \
@@ -172,6 +224,16 @@ __global__ __launch_bounds__(TPB) void eval_cons_kernel(int64_t m, const int64_t
         hipLaunchKernelGGL(kern, dim3(grid_for(len)), dim3(TPB), 0, ctx->stream, __VA_ARGS__);  \
         LAUNCH_CHECK(ctx);                                                                      \
     } while (0)
+
+// y(m) = alpha A x(nx) + beta y   /   y(nx) = alpha A' x(m) + beta y, from whichever layout is held
+static int32_t apply_A(madqp_kkt* k, double alpha, const double* x, double beta, double* y) {
+    if (k->A) return madqp_gemv_impl(k->ctx, 0, k->m, k->nx, alpha, k->A, k->lda, x, beta, y, MADQP_PROF_GEMV);
+    return madqp_gemv_impl(k->ctx, 1, k->nx, k->m, alpha, k->At, k->ldat, x, beta, y, MADQP_PROF_GEMV);
+}
+static int32_t apply_At(madqp_kkt* k, double alpha, const double* x, double beta, double* y) {
+    if (k->A) return madqp_gemv_impl(k->ctx, 1, k->m, k->nx, alpha, k->A, k->lda, x, beta, y, MADQP_PROF_GEMV);
+    return madqp_gemv_impl(k->ctx, 0, k->nx, k->m, alpha, k->At, k->ldat, x, beta, y, MADQP_PROF_GEMV);
+}
 
 extern "C" int32_t madqp_kkt_destroy(madqp_kkt* k) {
     if (!k) return MADQP_OK;
@@ -183,18 +245,18 @@ extern "C" int32_t madqp_kkt_destroy(madqp_kkt* k) {
     if (k->theta) (void)hipFree(k->theta);
     if (k->t) (void)hipFree(k->t);
     if (k->u) (void)hipFree(k->u);
+    if (k->dn) (void)hipFree(k->dn);
+    if (k->tn) (void)hipFree(k->tn);
     delete k;
     return MADQP_OK;
 }
 
-extern "C" int32_t madqp_kkt_create(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
-                                    const int64_t* ind_ineq_host, const double* H, int64_t ldh,
-                                    const double* A, int64_t lda, madqp_kkt** out) {
-    if (!ctx) return MADQP_ERR_ARG;
+static int32_t kkt_create_common(madqp_ctx* ctx, int mode, int64_t nx, int64_t m, int64_t ns,
+                                 const int64_t* ind_ineq_host, const double* H, int64_t ldh,
+                                 const double* A, int64_t lda, const double* At, int64_t ldat,
+                                 madqp_kkt** out) {
     ARG_TRY(ctx, out && nx >= 0 && m >= 0 && ns >= 0 && ns <= m);
     ARG_TRY(ctx, ns == 0 || ind_ineq_host);
-    ARG_TRY(ctx, !H || ldh >= nx);
-    ARG_TRY(ctx, m == 0 || nx == 0 || (A && lda >= nx));
     *out = nullptr;
     std::vector<int64_t> slot((size_t)std::max<int64_t>(m, 1), -1);
     for (int64_t k = 0; k < ns; ++k) {
@@ -207,6 +269,7 @@ extern "C" int32_t madqp_kkt_create(madqp_ctx* ctx, int64_t nx, int64_t m, int64
     if (!k) return madqp_fail(ctx, MADQP_ERR_ALLOC, "host allocation failed");
     memset(k, 0, sizeof(*k));
     k->ctx = ctx;
+    k->mode = mode;
     k->nx = nx;
     k->m = m;
     k->ns = ns;
@@ -214,14 +277,22 @@ extern "C" int32_t madqp_kkt_create(madqp_ctx* ctx, int64_t nx, int64_t m, int64
     k->ldh = ldh;
     k->A = A;
     k->lda = lda;
-    k->ldk = std::max<int64_t>(16, (nx + 15) / 16 * 16);
+    k->At = At;
+    k->ldat = ldat;
+    const int64_t dim = (mode == KKT_NORMAL) ? m : nx;  // order of the matrix that is factorised
+    const int64_t n = nx + ns;
+    k->ldk = std::max<int64_t>(16, (dim + 15) / 16 * 16);
     const size_t mb = (size_t)std::max<int64_t>(m, 1) * sizeof(double);
-    hipError_t e = hipMalloc(&k->K, (size_t)k->ldk * std::max<int64_t>(nx, 1) * sizeof(double));
+    const size_t nb = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
+    // +128 doubles of slack after the last column (room for 16-byte tile loads at the edge)
+    hipError_t e = hipMalloc(&k->K, ((size_t)k->ldk * std::max<int64_t>(dim, 1) + 128) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&k->d_ind_ineq, (size_t)std::max<int64_t>(ns, 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(&k->d_slot, (size_t)std::max<int64_t>(m, 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(&k->theta, mb);
     if (e == hipSuccess) e = hipMalloc(&k->t, mb);
     if (e == hipSuccess) e = hipMalloc(&k->u, mb);
+    if (e == hipSuccess && mode == KKT_NORMAL) e = hipMalloc(&k->dn, nb);
+    if (e == hipSuccess && mode == KKT_NORMAL) e = hipMalloc(&k->tn, nb);
     if (e == hipSuccess && ns)
         e = hipMemcpy(k->d_ind_ineq, ind_ineq_host, ns * sizeof(int64_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && m)
@@ -231,13 +302,30 @@ extern "C" int32_t madqp_kkt_create(madqp_ctx* ctx, int64_t nx, int64_t m, int64
         return madqp_fail(ctx, MADQP_ERR_ALLOC, "madqp_kkt_create(nx=%lld, m=%lld): %s",
                           (long long)nx, (long long)m, hipGetErrorString(e));
     }
-    int32_t r = madqp_chol_create(ctx, nx, &k->chol);
+    int32_t r = madqp_chol_create(ctx, dim, &k->chol);
     if (r) {
         madqp_kkt_destroy(k);
         return r;
     }
     *out = k;
     return MADQP_OK;
+}
+
+extern "C" int32_t madqp_kkt_create(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
+                                    const int64_t* ind_ineq_host, const double* H, int64_t ldh,
+                                    const double* A, int64_t lda, madqp_kkt** out) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, !H || ldh >= nx);
+    ARG_TRY(ctx, m == 0 || nx == 0 || (A && lda >= nx));
+    return kkt_create_common(ctx, KKT_CONDENSED, nx, m, ns, ind_ineq_host, H, ldh, A, lda, nullptr, 0, out);
+}
+
+extern "C" int32_t madqp_kkt_create_normal(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
+                                           const int64_t* ind_ineq_host, const double* At,
+                                           int64_t ldat, madqp_kkt** out) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, m == 0 || nx == 0 || (At && ldat >= m));
+    return kkt_create_common(ctx, KKT_NORMAL, nx, m, ns, ind_ineq_host, nullptr, 0, nullptr, 0, At, ldat, out);
 }
 
 static int32_t check_kkt_state(madqp_kkt* k, const madqp_state* st) {
@@ -252,6 +340,17 @@ extern "C" int32_t madqp_kkt_build(madqp_kkt* k, const madqp_state* st) {
     int32_t r = check_kkt_state(k, st);
     if (r) return r;
     madqp_ctx* ctx = k->ctx;
+    if (k->mode == KKT_NORMAL) {
+        // S = A diag(D_x) A' + diag(D_s on inequality rows),  D = 1/Sigma; du_diag is NOT added
+        // (src/KKT/normalkkt.jl:166-180, src/utils.jl:266-298)
+        {
+            ProfScope ps(ctx, MADQP_PROF_VEC);
+            if (st->n) KLAUNCH(recip_kernel, st->n, st->n, st->pr_diag, k->dn);
+            if (k->m) KLAUNCH(slack_diag_kernel, k->m, k->m, k->nx, k->d_slot, k->dn, k->theta);
+        }
+        return madqp_syrk_assemble(ctx, k->m, k->nx, k->At, k->ldat, k->dn, nullptr, 0, k->theta, k->K,
+                                   k->ldk);
+    }
     if (k->m) {
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(theta_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, k->theta);
@@ -273,6 +372,25 @@ extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* 
     double* wx = w;
     double* wy = w + st->n;
     if ((r = madqp_reduce_rhs(ctx, st, w))) return r;
+    if (k->mode == KKT_NORMAL) {  // src/KKT/normalkkt.jl:185-201
+        {
+            ProfScope ps(ctx, MADQP_PROF_VEC);
+            if (st->n) KLAUNCH(div_kernel, st->n, st->n, wx, st->pr_diag, k->tn);  // r1 = Sigma^-1 wx
+        }
+        if ((r = apply_A(k, 1.0, k->tn, 0.0, k->u))) return r;
+        if (k->m) {
+            ProfScope ps(ctx, MADQP_PROF_VEC);
+            KLAUNCH(normal_rhs_kernel, k->m, k->m, k->d_slot, k->u, k->tn + k->nx, wy, wy);  // A r1 - r2
+        }
+        if ((r = madqp_chol_solve(k->chol, wy))) return r;  // wy = dy
+        if ((r = apply_At(k, 1.0, wy, 0.0, k->tn))) return r;
+        {
+            ProfScope ps(ctx, MADQP_PROF_VEC);
+            if (k->ns) KLAUNCH(jt_slack_kernel, k->ns, k->ns, k->d_ind_ineq, wy, k->tn + k->nx, 1.0, 0.0);
+            if (st->n) KLAUNCH(normal_back_kernel, st->n, st->n, k->tn, st->pr_diag, wx);
+        }
+        return madqp_finish_aug_solve(ctx, st, w);
+    }
     if (k->m) {
         {
             ProfScope ps(ctx, MADQP_PROF_VEC);
@@ -280,13 +398,11 @@ extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* 
                     k->t, k->u);
         }
         // rhs_x = r1_x + A' (theta t)
-        if ((r = madqp_gemv_impl(ctx, 1, k->m, k->nx, 1.0, k->A, k->lda, k->u, 1.0, wx, MADQP_PROF_GEMV)))
-            return r;
+        if ((r = apply_At(k, 1.0, k->u, 1.0, wx))) return r;
     }
     if ((r = madqp_chol_solve(k->chol, wx))) return r;
     if (k->m) {
-        if ((r = madqp_gemv_impl(ctx, 0, k->m, k->nx, 1.0, k->A, k->lda, wx, 0.0, k->u, MADQP_PROF_GEMV)))
-            return r;
+        if ((r = apply_A(k, 1.0, wx, 0.0, k->u))) return r;
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(decondense_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, k->theta, k->t, k->u,
                 wx, wy);
@@ -299,8 +415,7 @@ extern "C" int32_t madqp_kkt_jtprod(madqp_kkt* k, double* out, const double* y) 
     madqp_ctx* ctx = k->ctx;
     ARG_TRY(ctx, (out && y) || (k->nx + k->ns == 0));
     int32_t r;
-    if ((r = madqp_gemv_impl(ctx, 1, k->m, k->nx, 1.0, k->A, k->lda, y, 0.0, out, MADQP_PROF_GEMV)))
-        return r;
+    if ((r = apply_At(k, 1.0, y, 0.0, out))) return r;
     if (k->ns) {
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(jt_slack_kernel, k->ns, k->ns, k->d_ind_ineq, y, out + k->nx, 1.0, 0.0);
@@ -316,8 +431,7 @@ extern "C" int32_t madqp_kkt_mul(madqp_kkt* k, const madqp_state* st, double* w,
     ARG_TRY(ctx, w && v);
     const int64_t nx = k->nx, n = st->n;
     // wx = alpha A_full' vy + beta wx  (+ alpha H vx)
-    if ((r = madqp_gemv_impl(ctx, 1, k->m, nx, alpha, k->A, k->lda, v + n, beta, w, MADQP_PROF_GEMV)))
-        return r;
+    if ((r = apply_At(k, alpha, v + n, beta, w))) return r;
     if (k->H && nx)
         if ((r = madqp_gemv_impl(ctx, 0, nx, nx, alpha, k->H, k->ldh, v, 1.0, w, MADQP_PROF_GEMV)))
             return r;
@@ -327,8 +441,7 @@ extern "C" int32_t madqp_kkt_mul(madqp_kkt* k, const madqp_state* st, double* w,
     }
     // wy = alpha A_full vx + beta wy
     if (k->m) {
-        if ((r = madqp_gemv_impl(ctx, 0, k->m, nx, 1.0, k->A, k->lda, v, 0.0, k->u, MADQP_PROF_GEMV)))
-            return r;
+        if ((r = apply_A(k, 1.0, v, 0.0, k->u))) return r;
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(mul_rows_kernel, k->m, k->m, k->d_slot, k->u, v + nx, w + n, alpha, beta);
     }
@@ -359,8 +472,7 @@ extern "C" int32_t madqp_kkt_eval(madqp_kkt* k, const madqp_state* st, const dou
         }
     }
     if (k->m) {
-        if ((r = madqp_gemv_impl(ctx, 0, k->m, nx, 1.0, k->A, k->lda, st->x, 0.0, st->c, MADQP_PROF_GEMV)))
-            return r;
+        if ((r = apply_A(k, 1.0, st->x, 0.0, st->c))) return r;
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(eval_cons_kernel, k->m, k->m, k->d_slot, st->x + nx, rhs, st->c);
     }

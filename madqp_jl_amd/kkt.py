@@ -115,3 +115,28 @@ class HIPCondensedKKTSystem:
     def eval_model(self, q, rhs, c0) -> float:
         """obj / grad! / cons! callbacks of the loop (src/solver.jl:166-169, 338-340)."""
         return self.be.kkt_eval(self._h, self.st, q, rhs, c0)
+
+
+class HIPNormalKKTSystem(HIPCondensedKKTSystem):
+    """The reference's own ``NormalKKTSystem`` (src/KKT/normalkkt.jl) on the device: normal equations
+    ``A Sigma^-1 A'`` (m x m), LP only (:45-48); equality rows need no dual regularization.
+
+    ``At``: (nx, m) tensor, row k = variable k contiguous (a Julia ``m x nx`` matrix as is); borrowed.
+    """
+
+    def __init__(self, backend, st: State, nx, ind_ineq, H, At):
+        if H is not None:
+            raise ValueError("The KKT system NormalKKTSystem supports only linear programs.")  # :45-48
+        self.be, self.st = backend, st
+        self.nx, self.m = int(nx), st.m
+        self.ind_ineq = [int(i) for i in ind_ineq]
+        self.ns = len(self.ind_ineq)
+        assert st.n == self.nx + self.ns
+        self.H, self.A, self.At = None, None, At
+        assert At.is_contiguous() and tuple(At.shape) == (self.nx, self.m)
+        self._h = backend.kkt_create_normal(self.nx, self.m, self.ind_ineq, At, max(self.m, 1))
+        self.linear_solver = HIPCholeskySolver(backend, self._h)
+        self.n_factorizations = 0
+
+    def is_inertia_correct(self, num_pos, num_zero, num_neg):  # src/KKT/normalkkt.jl:132-134
+        return num_zero == 0 and num_pos == self.m

@@ -42,6 +42,7 @@ class IPMOptions:
         tol=1e-8, max_iter=3000, scaling=True, bound_push=1e-2, bound_fac=1e-2,
         bound_relax_factor=1e-8, max_ncorr=0, mu_init=1e-1, mu_min=1e-11,
         tol_linear_solve=1e-8, check_residual=False, rethrow_error=False, print_level=0,
+        kkt_system="condensed",  # "condensed" (HIPCondensedKKTSystem) or "normal" (HIPNormalKKTSystem, LP)
     )
 
     def __init__(self, **kw):

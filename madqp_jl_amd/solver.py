@@ -17,7 +17,7 @@ import math
 import numpy as np
 import torch
 
-from .kkt import HIPCondensedKKTSystem
+from .kkt import HIPCondensedKKTSystem, HIPNormalKKTSystem
 from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, FixedRegularization,
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
 from .qp import DeviceQP
@@ -72,7 +72,12 @@ class MPCSolver:
         self.st = backend.new_state(self.n, self.m, ic["ind_lb"], ic["ind_ub"])
         self.nlb, self.nub = self.st.nlb, self.st.nub
         reg = self.opt.regularization
-        if len(self.ind_eq) and (isinstance(reg, NoRegularization) or reg.delta_d >= 0.0):
+        if self.opt.kkt_system not in ("condensed", "normal"):
+            raise ValueError(f"unknown kkt_system {self.opt.kkt_system!r}")
+        if self.opt.kkt_system == "normal" and qp.H is not None:
+            raise ValueError("The KKT system NormalKKTSystem supports only linear programs.")
+        if self.opt.kkt_system == "condensed" and len(self.ind_eq) and (
+                isinstance(reg, NoRegularization) or reg.delta_d >= 0.0):
             raise ValueError("the condensed KKT system needs dual regularization delta_d < 0 "
                              "when the problem has equality constraints")
         self.obj_scale, self.con_scale = 1.0, None
@@ -269,7 +274,11 @@ class MPCSolver:
                 self.q = self.obj_scale * qp.q
         if self.kkt is not None:
             self.kkt.close()
-        self.kkt = HIPCondensedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)
+        if opt.kkt_system == "normal":
+            self.At = self.A.t().contiguous()  # (nx, m): the layout the normal-equations GEMM consumes
+            self.kkt = HIPNormalKKTSystem(be, st, nx, self.ind_ineq, self.H, self.At)
+        else:
+            self.kkt = HIPCondensedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)
         self.kkt.initialize()  # :162
         self.init_regularization()  # :163
         self.eval_model()  # :166-169

@@ -22,7 +22,8 @@ def _np(t):
 
 
 class FakeKKT:
-    def __init__(self, nx, m, ind_ineq, H, A):
+    def __init__(self, nx, m, ind_ineq, H, A, normal=False):
+        self.normal = normal
         self.nx, self.m = nx, m
         self.ind_ineq = np.asarray(ind_ineq, dtype=np.int64)
         self.ns = len(self.ind_ineq)
@@ -277,6 +278,9 @@ class FakeBackend:
     def kkt_create(self, nx, m, ind_ineq, H, ldh, A, lda):
         return FakeKKT(nx, m, ind_ineq, H, A)
 
+    def kkt_create_normal(self, nx, m, ind_ineq, At, ldat):
+        return FakeKKT(nx, m, ind_ineq, None, At.t(), normal=True)
+
     def kkt_destroy(self, h):
         pass
 
@@ -291,6 +295,13 @@ class FakeBackend:
         return th
 
     def kkt_build(self, h, st):
+        if h.normal:  # src/KKT/normalkkt.jl:166-180
+            D = 1.0 / _np(st.pr_diag)
+            K = (h.A * D[: h.nx]) @ h.A.T
+            isq = h.slot >= 0
+            K[np.flatnonzero(isq), np.flatnonzero(isq)] += D[h.nx + h.slot[isq]]
+            h.K = K
+            return
         h.theta = self._theta(h, st)
         K = (h.A.T * h.theta) @ h.A
         if h.H is not None:
@@ -313,6 +324,17 @@ class FakeBackend:
         wx, wy, _, _ = self._parts(st, w)
         nx, S = h.nx, _np(st.pr_diag)
         isq = h.slot >= 0
+        if h.normal:  # src/KKT/normalkkt.jl:185-201
+            r1 = wx / S
+            u = h.A @ r1[:nx]
+            u[isq] -= r1[nx + h.slot[isq]]
+            wy[:] = sla.cho_solve(h.chol, u - wy, check_finite=False)
+            t = np.empty(st.n)
+            t[:nx] = h.A.T @ wy
+            t[nx:] = -wy[h.ind_ineq]
+            wx[:] = (wx - t) / S
+            self.finish_aug_solve(st, w)
+            return
         t = wy.copy()
         t[isq] += wx[nx + h.slot[isq]] / S[nx + h.slot[isq]]
         wx[:nx] = wx[:nx] + h.A.T @ (h.theta * t)

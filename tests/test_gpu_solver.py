@@ -188,3 +188,44 @@ def test_full_size_properties_n5k(hip):
     Ax = (dq.A @ torch.as_tensor(x, device=hip.device)).cpu().numpy()
     assert np.all(Ax >= -1e-6) and np.all(Ax <= 1 + 1e-6)
     s.kkt.close()
+
+
+@pytest.mark.parametrize("case", ["simple_lp", "lp_30_12", "lp_400_150"])
+def test_normal_kkt_system(hip, case):
+    """The reference's own NormalKKTSystem formulation on the device (kkt_system="normal"), with the
+    reference's default regularization (delta_d = 0) and equality rows: test/runtests.jl:165-180."""
+    qp = {"simple_lp": Q.simple_lp, "lp_30_12": lambda: Q.synthetic_qp(20250615, 30, 12, "lp"),
+          "lp_400_150": lambda: Q.synthetic_qp(5, 400, 150, "lp")}[case]()
+    reg, oreg = M.FixedRegularization(1e-8, 0.0), mpc.FixedRegularization(1e-8, 0.0)
+    r = solve_hip(qp, hip, kkt_system="normal", regularization=reg)
+    ref = mpc.solve(qp, kkt_system="normal", regularization=oreg)
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
+    compare_traces(r["trace"], ref["trace"], f"normal {case}")
+    assert close(r["objective"], ref["objective"], 1e-9)
+    assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+    if case == "simple_lp":
+        assert abs(r["objective"] - 1.0) < 1e-8 and np.allclose(r["solution"], [0.5, 0.5], atol=1e-8)
+    # cross-formulation equality (test/runtests.jl:165-180): normal == condensed on the same LP
+    rc = solve_hip(qp, hip)
+    assert abs(rc["objective"] - r["objective"]) < 1e-6 and np.max(np.abs(rc["solution"] - r["solution"])) < 1e-6
+
+
+def test_normal_kkt_conformance(hip):
+    """MadNLPTests.test_kkt_system on NormalKKTSystem (test/runtests.jl:149-163): K * solve(b) == b."""
+    rng = np.random.default_rng(1)
+    qp = Q.synthetic_qp(11, 120, 45, "lp")
+    qp.lcon[[2, 7]] = qp.ucon[[2, 7]] = 0.3
+    s = M.MPCSolver(to_device(qp, hip), hip, kkt_system="normal")
+    s.initialize()
+    st = s.st
+    hip.set_aug_diagonal_reg(st, 1e-8, 0.0)
+    s.kkt.factorize_wrapper()
+    assert s.kkt.linear_solver.is_factorized()
+    b = rng.standard_normal(st.ntot)
+    st.p.copy_(torch.as_tensor(b))
+    hip.copy(st.p, st.d)
+    s.kkt.solve(st.d)
+    hip.fill(0.0, st.w1)
+    s.kkt.mul(st.w1, st.d, 1.0, 0.0)
+    assert np.max(np.abs(st.w1.cpu().numpy() - b)) / max(1.0, np.max(np.abs(b))) < 1e-9
+    s.kkt.close()

@@ -130,3 +130,23 @@ def test_max_iter_status():
     qp = Q.dummy_qp(10, 5)
     _, r = run(qp, max_iter=2)
     assert r["status"] == M.MAXIMUM_ITERATIONS_EXCEEDED and r["iter"] == 2
+
+
+@pytest.mark.parametrize("make", [lambda: Q.simple_lp(), lambda: Q.synthetic_qp(20250615, 30, 12, "lp")])
+def test_normal_kkt_driver_matches_oracle(make):
+    """kkt_system="normal": the reference's own NormalKKTSystem formulation (src/KKT/normalkkt.jl) with the
+    reference's default regularization FixedRegularization(1e-8, 0.0) -- equality rows included."""
+    qp = make()
+    _, r = run(qp, kkt_system="normal", regularization=M.FixedRegularization(1e-8, 0.0))
+    ref = mpc.solve(qp, kkt_system="normal", regularization=mpc.FixedRegularization(1e-8, 0.0))
+    assert r["status"] == M.SOLVE_SUCCEEDED
+    assert_same_trace(r, ref)
+    assert np.max(np.abs(r["solution"] - ref["solution"])) < 1e-7
+
+
+def test_normal_kkt_rejects_qp():
+    """src/KKT/normalkkt.jl:45-48."""
+    qp = Q.hs21()
+    dq = M.DeviceQP.from_numpy("cpu", qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0)
+    with pytest.raises(ValueError):
+        M.MPCSolver(dq, FakeBackend(), kkt_system="normal")
