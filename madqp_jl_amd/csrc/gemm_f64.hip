@@ -275,15 +275,19 @@ __device__ __forceinline__ void mainloop_dma(const GemmArgs& g, int64_t i0, int6
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_DOUBLES];
     const GemmArgs& g = ka.g;
-    // XCD-contiguous remap of the workgroup id (bijective for any grid size)
+    // Tile selection: the table is cut into 8 contiguous chunks, one per XCD (workgroup ids equal
+    // mod 8 share an XCD under the observed round-robin dispatch; claiming tiles by the real
+    // HW_REG_XCC_ID gave the same traffic and time, so the static map is kept).  Speed only: any
+    // placement computes the same result.
     const int bid = blockIdx.x, T = ka.ntiles;
     const int xcd = bid & 7, q = T >> 3, r = T & 7;
+    const int tid = threadIdx.x;
     const int t = ka.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
     const int32_t packed = ka.table[t];
     const int64_t i0 = (int64_t)(packed >> 16) * BM;
     const int64_t j0 = (int64_t)(packed & 0xFFFF) * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, lives in an SGPR
     const int wi = wave & 1, wj = wave >> 1;
 #ifdef MADQP_STAMPS
@@ -419,9 +423,25 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls) {
     extern unsigned long long* madqp_stamp_buffer;
     ka.stamps = madqp_stamp_buffer;
 #endif
+    // Long launches are cut into segments of 64 rounds of resident workgroups.  Equal-cost tiles
+    // that start together sweep K in lockstep and share their operand panels through the XCD's
+    // L2; over many rounds that lockstep diffuses away (measured at n = 50000, K = 20480: 0.93-1.3 TB
+    // fetched by one assembly launch, 0.75 TB when re-synchronised every 64 rounds, floor 0.68 TB).
+    // The last round of a segment finishes almost simultaneously: +0.25 % time.
+    static const int seg_rounds = getenv("MADQP_GEMM_SEG_ROUNDS") ? atoi(getenv("MADQP_GEMM_SEG_ROUNDS")) : 64;
+    const int64_t seg = seg_rounds > 0 ? (int64_t)seg_rounds * ctx->gemm_slots : (int64_t)ka.ntiles;
+    const int32_t* table0 = ka.table;
+    const int32_t total = ka.ntiles;
     ProfScope ps(ctx, prof_cls);
-    hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3(ka.ntiles), dim3(NTHREADS), 0, ctx->stream, ka);
-    LAUNCH_CHECK(ctx);
+    for (int64_t off = 0; off < total; off += seg) {
+        int64_t cnt = std::min<int64_t>(seg, total - off);
+        if (total - off - cnt < seg / 4) cnt = total - off;  // no tiny last segment
+        ka.table = table0 + off;
+        ka.ntiles = (int32_t)cnt;
+        hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3(ka.ntiles), dim3(NTHREADS), 0, ctx->stream, ka);
+        LAUNCH_CHECK(ctx);
+        if (cnt == total - off) break;
+    }
     return MADQP_OK;
 }
 

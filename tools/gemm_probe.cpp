@@ -102,9 +102,11 @@ int main() {
         run_panel(ctx, 40960, 20480, 2048, 3);
         run_panel(ctx, 40960, 32768, 1024, 0);
         run_panel(ctx, 40960, 8192, 2048, 0);
-        run(ctx, 24576, 20480, true, true);
+        const char* e = getenv("PROBE_N");
+        run(ctx, e ? atol(e) : 24576, 20480, true, getenv("PROBE_NOBASE") ? false : true);
     } else if (getenv("PROBE_ONE")) {
-        run(ctx, 24576, 8192, true, true);
+        const char* e = getenv("PROBE_N");
+        run(ctx, e ? atol(e) : 24576, 20480, true, getenv("PROBE_NOBASE") ? false : true);
     } else {
         run(ctx, 16384, 4096, false, false);
         run(ctx, 16384, 4096, true, true);
