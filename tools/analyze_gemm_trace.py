@@ -59,15 +59,22 @@ f = glob.glob(sys.argv[1])[0]
 rows = [r for r in csv.DictReader(open(f)) if "gemm_tn" in r["Kernel_Name"]]
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in rows]
 grids = [int(r["Grid_Size_X"]) // 256 for r in rows]
-print(len(sched), "gemm launches per factorization;", len(rows), "in trace; first grid", grids[0])
-seg = list(zip(sched, durs[1:1 + len(sched)], grids[1:1 + len(sched)]))
+tm_all = (n + 127) // 128
+syrk_tiles = tm_all * (tm_all + 1) // 2
+nsy, acc = 0, 0
+while acc < syrk_tiles:  # the assembly may be cut into several launches (segments)
+    acc += grids[nsy]
+    nsy += 1
+print(len(sched), "gemm launches per factorization;", len(rows), "in trace;", nsy, "assembly launches")
+seg = list(zip(sched, durs[nsy:nsy + len(sched)], grids[nsy:nsy + len(sched)]))
 agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for (kind, M, N, K, t), d, g in seg:
     assert t == g, (kind, M, N, K, t, g)
     agg[kind][0] += 2.0 * t * 128 * 128 * K
     agg[kind][1] += d
     agg[kind][2] += 1
-print("syrk", round(durs[0], 1), "ms", round(2.0 * grids[0] * 128 * 128 * 20000 / durs[0] * 1e-9, 1), "TF")
+sy_ms = sum(durs[:nsy])
+print("syrk", round(sy_ms, 1), "ms", round(2.0 * syrk_tiles * 128 * 128 * 20000 / sy_ms * 1e-9, 1), "TF")
 for k, (fl, d, c) in agg.items():
     print(k, c, "launches", round(d, 1), "ms", round(fl / d * 1e-9, 1), "TF (computed flops, full diagonal tiles)")
 print("outer panels: M, W, K, tiles, ms, TF, tiles/512")
