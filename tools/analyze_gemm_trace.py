@@ -68,8 +68,10 @@ while acc < syrk_tiles:  # the assembly may be cut into several launches (segmen
 print(len(sched), "gemm launches per factorization;", len(rows), "in trace;", nsy, "assembly launches")
 seg = list(zip(sched, durs[nsy:nsy + len(sched)], grids[nsy:nsy + len(sched)]))
 agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
+mismatch = 0
 for (kind, M, N, K, t), d, g in seg:
-    assert t == g, (kind, M, N, K, t, g)
+    mismatch += int(t != g)  # replayed schedule vs traced grid (labels are approximate if > 0)
+    t = g
     agg[kind][0] += 2.0 * t * 128 * 128 * K
     agg[kind][1] += d
     agg[kind][2] += 1
@@ -77,6 +79,7 @@ sy_ms = sum(durs[:nsy])
 print("syrk", round(sy_ms, 1), "ms", round(2.0 * syrk_tiles * 128 * 128 * 20000 / sy_ms * 1e-9, 1), "TF")
 for k, (fl, d, c) in agg.items():
     print(k, c, "launches", round(d, 1), "ms", round(fl / d * 1e-9, 1), "TF (computed flops, full diagonal tiles)")
+print("launches whose replayed tile count differs from the trace:", mismatch)
 print("outer panels: M, W, K, tiles, ms, TF, tiles/512")
 for (kind, M, N, K, t), d, g in seg:
     if kind == "outer":
