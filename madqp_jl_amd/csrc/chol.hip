@@ -44,7 +44,7 @@ __device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int
                                                      int32_t* __restrict__ info, int32_t col0,
                                                      int lane) {
     const int r = lane & 15;
-    double a[SB];
+    double a[SB], rdk[SB];  // rdk[k] = 1 / L_kk (wave uniform), reused by the inversion
 #pragma unroll
     for (int c = 0; c < SB; ++c) a[c] = S[(b + c) * LDS_LD + b + r];
 #pragma unroll
@@ -54,14 +54,17 @@ __device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int
             if (lane == 0) atomicCAS(info, 0, col0 + b + k + 1);
             akk = 1.0;
         }
-        const double d = sqrt(akk);
-        const double rd = 1.0 / d;
+        // this 16-step chain is the critical path of the whole factorisation: one rsqrt instead of
+        // sqrt + divide, fused multiply-adds for the rank-1 update
+        const double rd = rsqrt(akk);
+        const double d = akk * rd;
+        rdk[k] = rd;
         const double lk = (r == k) ? d : a[k] * rd;
         a[k] = lk;
 #pragma unroll
         for (int c = k + 1; c < SB; ++c) {
             const double lck = readlane_f64(lk, c);
-            a[c] -= lk * lck;
+            a[c] = __builtin_fma(-lk, lck, a[c]);
         }
     }
     if (lane < SB) {
@@ -74,10 +77,10 @@ __device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int
     double w[SB];
 #pragma unroll
     for (int rr = 0; rr < SB; ++rr) {
-        const double inv = 1.0 / readlane_f64(a[rr], rr);
+        const double inv = rdk[rr];
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < rr; ++k) acc += readlane_f64(a[k], rr) * w[k];
+        for (int k = 0; k < rr; ++k) acc = __builtin_fma(readlane_f64(a[k], rr), w[k], acc);
         w[rr] = (rr == cc) ? inv : ((rr > cc) ? -(acc * inv) : 0.0);
     }
     if (lane < SB) {
@@ -213,18 +216,21 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
     }
 }
 
-// Diagonal step of a triangular sweep as a 128 x 128 mat-vec with the inverse block:
-//   forward :  b_j <- W_jj  b_j          img = Wcm  (img[i + j*NB] = W(i,j))
-//   backward:  b_j <- W_jj' (b_j - t)    img = Wrm  (img[i + j*NB] = W(j,i))
-// 1024 threads: 8 column slices of 16 per output row, 16 independent coalesced loads per thread
-// (the kernel sits on the critical path of the sweep: latency, not bandwidth).
-__global__ __launch_bounds__(1024) void trsv_diag_kernel(const double* __restrict__ img,
-                                                         double* __restrict__ b,
-                                                         const double* __restrict__ t, int nb) {
-    __shared__ double vs[NB];
-    __shared__ double part[8][NB];
+// ---- triangular sweeps: one launch per 128-column block ------------------------------------
+// Both sweeps are "right-looking": as soon as the solution of block j is known it is applied to
+// the part of the vector not yet solved, so every workgroup of the launch finishes its outputs
+// alone (no cross-workgroup reduction).  Each workgroup recomputes the small diagonal product
+//   x_j = W_jj v_j (forward, W column-major image)   /   x_j = W_jj' v_j (backward, row-major image)
+// itself (128 x 128, the inverse block is shared through L2) instead of waiting for a separate
+// launch; workgroup 0 stores x_j, workgroups g >= 1 update one 128-entry slice of the vector:
+//   forward :  b[R] -= L[R, J] x_j      R = 128 rows below the block
+//   backward:  y[C] -= L[J, C]' x_j     C = 128 columns left of the block
+// The vector being updated and the vector receiving the solution are different arrays, so no
+// workgroup reads what another one writes.  4 n^2 bytes of L per sweep: HBM bound.
+__device__ __forceinline__ void block_matvec(const double* __restrict__ img, const double* __restrict__ v,
+                                             int w, double* vs, double (*part)[NB], double* xs) {
     const int i = threadIdx.x & (NB - 1), p = threadIdx.x >> 7;
-    if (threadIdx.x < NB) vs[i] = (i < nb) ? (b[i] - (t ? t[i] : 0.0)) : 0.0;
+    if (threadIdx.x < NB) vs[i] = (i < w) ? v[i] : 0.0;
     __syncthreads();
     double acc = 0.0;
 #pragma unroll
@@ -234,11 +240,81 @@ __global__ __launch_bounds__(1024) void trsv_diag_kernel(const double* __restric
     }
     part[p][i] = acc;
     __syncthreads();
-    if (threadIdx.x < NB && i < nb) {
-        double s = part[0][i];
+    if (threadIdx.x < NB) {
+        double sum = part[0][i];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) s += part[q][i];
-        b[i] = s;
+        for (int q = 1; q < 8; ++q) sum += part[q][i];
+        xs[i] = sum;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void trsv_fwd_step_kernel(const double* __restrict__ L, int64_t lda,
+                                                             const double* __restrict__ Wcm,
+                                                             double* __restrict__ b,
+                                                             double* __restrict__ yout, int64_t jb,
+                                                             int w, int64_t n) {
+    __shared__ double vs[NB], xs[NB];
+    __shared__ double part[8][NB];
+    block_matvec(Wcm, b + jb, w, vs, part, xs);
+    const int i = threadIdx.x & (NB - 1), p = threadIdx.x >> 7;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < w) yout[jb + threadIdx.x] = xs[threadIdx.x];
+        return;
+    }
+    const int64_t row = jb + w + (int64_t)(blockIdx.x - 1) * NB + i;
+    double acc = 0.0;
+    if (row < n) {
+        const double* Lp = L + row + jb * lda;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = p * 16 + q;
+            if (c < w) acc += Lp[(int64_t)c * lda] * xs[c];
+        }
+    }
+    part[p][i] = acc;
+    __syncthreads();
+    if (threadIdx.x < NB && row < n) {
+        double sum = part[0][i];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) sum += part[q][i];
+        b[row] -= sum;
+    }
+}
+
+__global__ __launch_bounds__(1024) void trsv_bwd_step_kernel(const double* __restrict__ L, int64_t lda,
+                                                             const double* __restrict__ Wrm,
+                                                             double* __restrict__ y,
+                                                             double* __restrict__ xout, int64_t jb,
+                                                             int w) {
+    __shared__ double vs[NB], xs[NB];
+    __shared__ double part[8][NB];
+    block_matvec(Wrm, y + jb, w, vs, part, xs);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < w) xout[jb + threadIdx.x] = xs[threadIdx.x];
+        return;
+    }
+    // 16 waves: wave v sums rows [64h, 64h+64) of the block for columns [16g, 16g+16), h = v&1, g = v>>1
+    const int lane = threadIdx.x & 63, v = threadIdx.x >> 6;
+    const int h = v & 1, g = v >> 1;
+    const int r = 64 * h + lane;
+    const int64_t c0 = (int64_t)(blockIdx.x - 1) * NB + 16 * g;  // columns left of the block (< jb)
+    const double xr = (r < w) ? xs[r] : 0.0;
+    const double* Lp = L + (jb + r) + c0 * lda;
+    double sums[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sums[q] = (r < w) ? Lp[(int64_t)q * lda] * xr : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        double t = sums[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (lane == 0) part[h][16 * g + q] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        const int64_t c = (int64_t)(blockIdx.x - 1) * NB + threadIdx.x;
+        y[c] -= part[0][threadIdx.x] + part[1][threadIdx.x];
     }
 }
 }  // namespace
@@ -407,41 +483,23 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
     if (!s->A) return madqp_fail(ctx, MADQP_ERR_STATE, "madqp_chol_solve before madqp_chol_factor");
     const int64_t n = s->n, lda = s->lda;
     const double* A = s->A;
-    // forward: L y = b
+    // forward: L y = b   (b updated in place below the block, y collected in s->tmp)
+    ProfScope ps(ctx, MADQP_PROF_TRSV);
     for (int64_t jb = 0; jb < n; jb += NB) {
         const int64_t w = std::min<int64_t>(NB, n - jb);
         const double* Wcm = s->winv + (jb / NB) * WBLK;
-        {
-            ProfScope ps(ctx, MADQP_PROF_TRSV);
-            hipLaunchKernelGGL(trsv_diag_kernel, dim3(1), dim3(1024), 0, ctx->stream, Wcm, rhs + jb,
-                               (const double*)nullptr, (int)w);
-            LAUNCH_CHECK(ctx);
-        }
         const int64_t below = n - jb - w;
-        if (below > 0) {
-            // b[below] -= L[below, jb:jb+w] * y_j : memory rows = the w columns, each `below` long
-            int32_t r = madqp_gemv_impl(ctx, 1, w, below, -1.0, A + (jb + w) + jb * lda, lda,
-                                        rhs + jb, 1.0, rhs + jb + w, MADQP_PROF_TRSV);
-            if (r) return r;
-        }
+        hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3((unsigned)(1 + (below + NB - 1) / NB)), dim3(1024), 0,
+                           ctx->stream, A, lda, Wcm, rhs, s->tmp, jb, (int)w, n);
+        LAUNCH_CHECK(ctx);
     }
-    // backward: L' x = y
+    // backward: L' x = y  (y = s->tmp updated in place left of the block, x written to rhs)
     const int64_t last = ((n - 1) / NB) * NB;
     for (int64_t jb = last; jb >= 0; jb -= NB) {
         const int64_t w = std::min<int64_t>(NB, n - jb);
         const double* Wrm = s->winv + (jb / NB) * WBLK + NB * NB;
-        const int64_t below = n - jb - w;
-        const double* t = nullptr;
-        if (below > 0) {
-            // t = L[below, jb:jb+w]' x[below]
-            int32_t r = madqp_gemv_impl(ctx, 0, w, below, 1.0, A + (jb + w) + jb * lda, lda,
-                                        rhs + jb + w, 0.0, s->tmp, MADQP_PROF_TRSV);
-            if (r) return r;
-            t = s->tmp;
-        }
-        ProfScope ps(ctx, MADQP_PROF_TRSV);
-        hipLaunchKernelGGL(trsv_diag_kernel, dim3(1), dim3(1024), 0, ctx->stream, Wrm, rhs + jb,
-                           t, (int)w);
+        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3((unsigned)(1 + jb / NB)), dim3(1024), 0, ctx->stream,
+                           A, lda, Wrm, s->tmp, rhs, jb, (int)w);
         LAUNCH_CHECK(ctx);
     }
     return MADQP_OK;
