@@ -393,6 +393,13 @@ static int32_t panel_update(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, i
     g.M = n - row0;
     g.N = width;
     g.K = row0 - k0;
+    // rows up to the padded order may be read when the leading dimension covers them (the KKT
+    // object allocates K that way): no partial tiles, stores stay masked to M x N
+    const int64_t npad = (n + NB - 1) / NB * NB;
+    if (lda >= npad) {
+        g.Mread = npad - row0;
+        g.Nread = std::min<int64_t>(npad - row0, (width + NB - 1) / NB * NB);
+    }
     g.diag_off = 0;
     g.lower_only = 1;
     return madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_GEMM);
@@ -426,6 +433,9 @@ static int32_t factor_block(madqp_chol* s, double* A, int64_t lda, int64_t jb, i
         g.M = n - jb - w;
         g.N = w;
         g.K = w;
+        const int64_t npad = (n + NB - 1) / NB * NB;
+        if (lda >= npad) g.Mread = npad - jb - w;
+        g.Nread = NB;  // the inverse block image is always 128 x 128, zero padded
         return madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_TRSM);
     }
     return MADQP_OK;

@@ -98,6 +98,8 @@ struct GemmArgs {
     const double* dvec;  // optional: added where (i + diag_off == j), indexed by j
     double alpha, beta;  // out = alpha*acc + beta*Cin (+ dvec)
     int64_t M, N, K;
+    int64_t Mread, Nread;  // rows of X / Y that may be READ (>= M, N; 0 = M, N): operands padded to a
+                           // multiple of 128 let edge tiles take the fast path, stores stay masked to M, N
     int64_t diag_off;  // global_row(i) - global_col(j) = i - j + diag_off
     int lower_only;    // 1: write only elements with i + diag_off >= j; skip tiles above
 };

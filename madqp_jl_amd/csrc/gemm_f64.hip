@@ -301,7 +301,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-    const bool interior = ka.fast_ok && (i0 + BM <= g.M) && (j0 + BN <= g.N) && (g.K % BK == 0);
+    const bool interior = ka.fast_ok && (i0 + BM <= (g.Mread ? g.Mread : g.M)) &&
+                          (j0 + BN <= (g.Nread ? g.Nread : g.N)) && (g.K % BK == 0);
     if (interior)
         mainloop_dma(g, i0, j0, lds, wi, wj, lane, wave, acc);
     else
@@ -446,28 +447,39 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls) {
 }
 
 namespace {
-// Ys[k, :] = w[k] * B[k, :]  (one streaming pass, 16 n kdim bytes): keeps the per-k scaling out of
-// the MFMA loop, where every VALU instruction costs matrix-pipe cycles.
-__global__ __launch_bounds__(256) void scale_rows_kernel(int64_t n, int64_t kdim,
+// S[k, :] = sqrt(w[k]) * B[k, :], zero padded to npad columns and kpad rows: one streaming pass
+// (16 n kdim bytes).  The assembly then is the plain product S'S with BOTH operands read from this
+// library-owned, 128-aligned image: no per-k scaling inside the MFMA loop (every VALU instruction
+// there costs matrix-pipe cycles), a single operand stream, and no partial tiles.
+__global__ __launch_bounds__(256) void scale_rows_kernel(int64_t n, int64_t npad, int64_t kdim,
                                                          const double* __restrict__ B, int64_t ldb,
                                                          const double* __restrict__ w,
-                                                         double* __restrict__ out, int64_t ldo, int vec) {
+                                                         double* __restrict__ out, int vec) {
     const int64_t k = blockIdx.y;
-    const double wk = w[k];
+    double* dst = out + k * npad;
+    if (k >= kdim) {  // zero rows up to a multiple of 16
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npad; i += (int64_t)gridDim.x * 256)
+            dst[i] = 0.0;
+        return;
+    }
+    const double wk = sqrt(w[k]);
     const double* src = B + k * ldb;
-    double* dst = out + k * ldo;
     if (vec) {
-        const int64_t pairs = n >> 1;
+        const int64_t pairs = npad >> 1, full = n >> 1;
         for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (int64_t)gridDim.x * 256) {
-            double2_t v = *reinterpret_cast<const double2_t*>(src + 2 * p);
-            v.x *= wk;
-            v.y *= wk;
+            double2_t v = {0.0, 0.0};
+            if (p < full) {
+                v = *reinterpret_cast<const double2_t*>(src + 2 * p);
+                v.x *= wk;
+                v.y *= wk;
+            } else if (2 * p < n) {
+                v.x = src[2 * p] * wk;
+            }
             *reinterpret_cast<double2_t*>(dst + 2 * p) = v;
         }
-        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1] * wk;
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-            dst[i] = src[i] * wk;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npad; i += (int64_t)gridDim.x * 256)
+            dst[i] = (i < n) ? src[i] * wk : 0.0;
     }
 }
 }  // namespace
@@ -484,10 +496,10 @@ extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, 
     g.ldx = ldb;
     g.Y = g.X;
     g.ldy = ldb;
+    g.K = kdim;
     if (w && kdim > 0 && n > 0) {
-        // scaled copy of the operand in the context's scratch (grow-only)
-        const int64_t ldo = (n + 1) / 2 * 2;
-        const size_t bytes = (size_t)kdim * ldo * sizeof(double);
+        const int64_t npad = (n + BM - 1) / BM * BM, kpad = (kdim + BK - 1) / BK * BK;
+        const size_t bytes = (size_t)kpad * npad * sizeof(double);
         if (bytes > ctx->scaled_bytes) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->d_scaled) HIP_TRY(ctx, hipFree(ctx->d_scaled));
@@ -502,13 +514,15 @@ extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, 
         const int vec = ((((uintptr_t)B) & 15) == 0) && (ldb % 2 == 0);
         {
             ProfScope ps(ctx, MADQP_PROF_VEC);
-            const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n / 2 + 255) / 256, 64));
-            hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, (unsigned)kdim), dim3(256), 0, ctx->stream, n,
-                               kdim, B, ldb, w, ctx->d_scaled, ldo, vec);
+            const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((npad / 2 + 255) / 256, 64));
+            hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, (unsigned)kpad), dim3(256), 0, ctx->stream, n,
+                               npad, kdim, B, ldb, w, ctx->d_scaled, vec);
             LAUNCH_CHECK(ctx);
         }
-        g.Y = ctx->d_scaled;
-        g.ldy = ldo;
+        g.X = g.Y = ctx->d_scaled;
+        g.ldx = g.ldy = npad;
+        g.Mread = g.Nread = npad;
+        g.K = kpad;
     }
     g.C = C;
     g.ldc = ldc;
@@ -519,7 +533,6 @@ extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, 
     g.beta = 1.0;
     g.M = n;
     g.N = n;
-    g.K = kdim;
     g.diag_off = 0;
     g.lower_only = 1;
     return madqp_gemm_tn(ctx, g, MADQP_PROF_SYRK);

@@ -281,11 +281,15 @@ static int32_t kkt_create_common(madqp_ctx* ctx, int mode, int64_t nx, int64_t m
     k->ldat = ldat;
     const int64_t dim = (mode == KKT_NORMAL) ? m : nx;  // order of the matrix that is factorised
     const int64_t n = nx + ns;
-    k->ldk = std::max<int64_t>(16, (dim + 15) / 16 * 16);
+    // leading dimension and column count padded to a multiple of 128 (zero filled): every GEMM tile
+    // of the factorisation is a full tile (see GemmArgs::Mread)
+    const int64_t dpad = std::max<int64_t>(128, (dim + 127) / 128 * 128);
+    k->ldk = dpad;
     const size_t mb = (size_t)std::max<int64_t>(m, 1) * sizeof(double);
     const size_t nb = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
     // +128 doubles of slack after the last column (room for 16-byte tile loads at the edge)
-    hipError_t e = hipMalloc(&k->K, ((size_t)k->ldk * std::max<int64_t>(dim, 1) + 128) * sizeof(double));
+    hipError_t e = hipMalloc(&k->K, ((size_t)k->ldk * dpad + 128) * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(k->K, 0, ((size_t)k->ldk * dpad + 128) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&k->d_ind_ineq, (size_t)std::max<int64_t>(ns, 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(&k->d_slot, (size_t)std::max<int64_t>(m, 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(&k->theta, mb);

@@ -96,14 +96,12 @@ int main() {
     madqp_ctx* ctx;
     if (madqp_ctx_create(0, nullptr, &ctx)) return 1;
     if (getenv("PROBE_PANEL")) {
-        run_panel(ctx, 40960, 20480, 2048, 0);
-        run_panel(ctx, 40960, 20480, 2048, 1);
-        run_panel(ctx, 40960, 20480, 2048, 2);
-        run_panel(ctx, 40960, 20480, 2048, 3);
-        run_panel(ctx, 40960, 32768, 1024, 0);
-        run_panel(ctx, 40960, 8192, 2048, 0);
-        const char* e = getenv("PROBE_N");
-        run(ctx, e ? atol(e) : 24576, 20480, true, getenv("PROBE_NOBASE") ? false : true);
+        run_panel(ctx, 49920, 20480, 2048, 0);
+        run_panel(ctx, 50000, 20480, 2048, 0);
+        run_panel(ctx, 49920, 30720, 1920, 0);
+        run_panel(ctx, 50000, 30720, 1920, 0);
+        run_panel(ctx, 49920, 40960, 2048, 0);
+        run_panel(ctx, 50000, 40960, 2048, 0);
     } else if (getenv("PROBE_ONE")) {
         const char* e = getenv("PROBE_N");
         run(ctx, e ? atol(e) : 24576, 20480, true, getenv("PROBE_NOBASE") ? false : true);
