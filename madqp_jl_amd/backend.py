@@ -78,13 +78,16 @@ class HipBackend:
 
     name = "hip"
 
-    def __init__(self, device_index: int = 0):
+    def __init__(self, device_index: int = 0, stream=None):
+        """``stream``: a ``torch.cuda.Stream`` to launch on (default: torch's current stream).  Torch ops
+        issued under ``torch.cuda.stream(stream)`` and library calls are then ordered on it."""
         if not torch.cuda.is_available():
             raise MadQPError("no HIP device visible: the MI355X path has no CPU fallback")
         self.lib = _lib.load_cdll()
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.stream = stream
+        stream = (stream or torch.cuda.current_stream(self.device)).cuda_stream
         h = C.c_void_p()
         rc = self.lib.madqp_ctx_create(device_index, C.c_void_p(stream), C.byref(h))
         if rc != 0:

@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 
 #include "common.h"
 
@@ -347,19 +348,34 @@ struct TableVal {
     int32_t* d;
     int32_t n;
 };
-// per-context cache of tile tables (contexts are used by one host thread at a time)
+// per-context cache of tile tables.  A context is used by one host thread at a time, different
+// contexts may live on different threads (batch sharding): the outer map is guarded by a mutex,
+// the inner map belongs to its context's thread (std::map nodes are address stable).
+std::mutex& table_mutex() {
+    static std::mutex m;
+    return m;
+}
 std::map<madqp_ctx*, std::map<TableKey, TableVal>>& table_cache() {
     static std::map<madqp_ctx*, std::map<TableKey, TableVal>> c;
     return c;
 }
+std::map<TableKey, TableVal>& tables_of(madqp_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(table_mutex());
+    return table_cache()[ctx];
+}
 }  // namespace
 
 void madqp_gemm_release_tables(madqp_ctx* ctx) {
-    auto& all = table_cache();
-    auto it = all.find(ctx);
-    if (it == all.end()) return;
-    for (auto& kv : it->second) (void)hipFree(kv.second.d);
-    all.erase(it);
+    std::map<TableKey, TableVal> mine;
+    {
+        std::lock_guard<std::mutex> lock(table_mutex());
+        auto& all = table_cache();
+        auto it = all.find(ctx);
+        if (it == all.end()) return;
+        mine.swap(it->second);
+        all.erase(it);
+    }
+    for (auto& kv : mine) (void)hipFree(kv.second.d);
 }
 
 int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls) {
@@ -371,7 +387,7 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls) {
     TableKey key{tiles_m, tiles_n,
                  (a.lower_only ? 1 : 0) | ((a.M % BM) != 0 ? 2 : 0) | ((a.N % BN) != 0 ? 4 : 0),
                  a.lower_only ? a.diag_off : 0};
-    auto& cache = table_cache()[ctx];
+    auto& cache = tables_of(ctx);
     auto it = cache.find(key);
     if (it == cache.end()) {
         std::vector<int32_t> tab;

@@ -229,3 +229,23 @@ def test_normal_kkt_conformance(hip):
     s.kkt.mul(st.w1, st.d, 1.0, 0.0)
     assert np.max(np.abs(st.w1.cpu().numpy() - b)) / max(1.0, np.max(np.abs(b))) < 1e-9
     s.kkt.close()
+
+
+def test_batch_of_independent_qps(hip):
+    """BASELINE configs[3] in miniature: a batch of independent QPs solved with several contexts /
+    streams in flight gives, problem by problem, the oracle's result (status, iterations, solution)."""
+    seeds = list(range(100, 112))
+
+    def make(be, i):
+        qp = Q.synthetic_qp(seeds[i], 64, 24)
+        return to_device(qp, be)
+
+    res = M.solve_batch(make, range(len(seeds)), streams=4, regularization=M.FixedRegularization(1e-8, -1e-8))
+    assert sorted(res) == list(range(len(seeds)))
+    for i, seed in enumerate(seeds):
+        ref = mpc.solve(Q.synthetic_qp(seed, 64, 24), kkt_system="condensed",
+                        regularization=mpc.FixedRegularization(1e-8, -1e-8))
+        r = res[i]
+        assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
+        assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+    assert M.shard(range(10), 1, 4) == [1, 5, 9] and M.shard(range(10), 0, 1) == list(range(10))

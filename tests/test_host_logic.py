@@ -150,3 +150,11 @@ def test_normal_kkt_rejects_qp():
     dq = M.DeviceQP.from_numpy("cpu", qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0)
     with pytest.raises(ValueError):
         M.MPCSolver(dq, FakeBackend(), kkt_system="normal")
+
+
+def test_batch_sharding_is_a_partition():
+    """QP b -> rank b mod N: every problem is owned by exactly one rank."""
+    for world in (1, 2, 3, 8):
+        owned = [M.shard(range(37), r, world) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(37))
+        assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1

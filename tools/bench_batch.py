@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Batch of independent QPs (BASELINE configs[3]: 1024 x (n=512, m=256)) on one GPU / one rank.
+
+    python tools/bench_batch.py [--batch 128] [--nx 512] [--m 256] [--streams 16]
+
+Under torch.distributed.run each rank takes problems rank, rank+N, ... (no communication) and rank 0
+reports the aggregate.  Prints one JSON line: QPs/s and IPM iterations/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--batch", type=int, default=128)
+    p.add_argument("--nx", type=int, default=512)
+    p.add_argument("--m", type=int, default=256)
+    p.add_argument("--streams", type=int, default=16)
+    p.add_argument("--seed", type=int, default=20250614 + 3)
+    a = p.parse_args()
+    import torch
+
+    world, rank, local_rank = bench.dist_setup("nccl")
+    import madqp_jl_amd as M
+
+    mine = M.shard(range(a.batch), rank, world)
+    make = lambda be, i: M.DeviceQP.synthetic(be, a.seed + i, a.nx, a.m)
+    opts = dict(max_iter=300, step_rule=M.AdaptiveStep(0.995), regularization=M.FixedRegularization(1e-8, -1e-8),
+                mu_min=1e-12)
+    M.solve_batch(make, mine[: min(len(mine), a.streams)], local_rank, a.streams, **opts)  # warm-up
+    bench.dist_barrier(world)
+    t0 = time.perf_counter()
+    res = M.solve_batch(make, mine, local_rank, a.streams, **opts)
+    bench.dist_barrier(world)
+    dt = bench.max_over_ranks(time.perf_counter() - t0, world, torch.device("cuda", local_rank))
+    iters = sum(r["iter"] for r in res.values())
+    ok = sum(r["status"] == M.SOLVE_SUCCEEDED for r in res.values())
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([iters, ok], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t)
+        iters, ok = int(t[0].item()), int(t[1].item())
+    if rank == 0:
+        print(json.dumps({"metric": "independent QPs solved per second", "value": a.batch / dt, "unit": "QP/s",
+                          "ipm_iterations_per_s": iters / dt, "n_gpus": world, "batch": a.batch,
+                          "solved": ok, "config": {"workload": f"{a.batch} x synthetic dense QP nx={a.nx} m={a.m}",
+                                                   "streams_per_gpu": a.streams}, "seconds": dt}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
