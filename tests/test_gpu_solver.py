@@ -249,3 +249,63 @@ def test_batch_of_independent_qps(hip):
         assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
         assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
     assert M.shard(range(10), 1, 4) == [1, 5, 9] and M.shard(range(10), 0, 1) == list(range(10))
+
+
+def test_full_size_c_main_properties(hip):
+    """BASELINE metric size (n_x = 50 000, m = 20 000): far beyond the oracle, so size-independent
+    properties through the same C ABI: (a) the on-device generator reproduces randomly chosen tiles of
+    A, H and q bit for bit; (b) the assembled condensed K equals H + Sigma + A' Theta A on sampled
+    entries; (c) the factorisation succeeds and every solve_system! of two IPM iterations (condense,
+    two triangular sweeps, decondense) satisfies the UNREDUCED KKT system (residual through mul!);
+    the iteration makes progress."""
+    nx, m, seed = 50000, 20000, 20250614 + 1
+    dq = M.DeviceQP.synthetic(hip, seed, nx, m)
+    rng = np.random.default_rng(0)
+    # (a) generator tiles
+    kA, kH = Q.stream_key(seed, Q.STREAM_A), Q.stream_key(seed, Q.STREAM_H)
+    for _ in range(4):
+        r0, c0 = int(rng.integers(0, m - 64)), int(rng.integers(0, nx - 64))
+        idx = (np.arange(r0, r0 + 64, dtype=np.uint64)[:, None] * np.uint64(nx)
+               + np.arange(c0, c0 + 64, dtype=np.uint64)[None, :])
+        np.testing.assert_array_equal(dq.A[r0:r0 + 64, c0:c0 + 64].cpu().numpy(),
+                                      Q.gen_normal(kA, idx.ravel()).reshape(64, 64))
+        i0, j0 = int(rng.integers(0, nx - 64)), int(rng.integers(0, nx - 64))
+        ii, jj = np.arange(i0, i0 + 64, dtype=np.uint64)[:, None], np.arange(j0, j0 + 64, dtype=np.uint64)[None, :]
+        ref = Q.gen_normal(kH, (np.minimum(ii, jj) * np.uint64(nx) + np.maximum(ii, jj)).ravel()).reshape(64, 64)
+        ref = ref * (1.0 / np.sqrt(nx))
+        ref[ii == jj] = 3.0 + ref[ii == jj]
+        np.testing.assert_array_equal(dq.H[i0:i0 + 64, j0:j0 + 64].cpu().numpy(), ref)
+    np.testing.assert_array_equal(dq.q[:1000].cpu().numpy(), Q.gen_q(seed, nx)[:1000])
+
+    s = M.MPCSolver(dq, hip, max_iter=300, step_rule=M.AdaptiveStep(0.995),
+                    regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12)
+    s.initialize()
+    assert s.last_residual_ratio < 1e-8
+    st = s.st
+    # (b) assembled K on sampled lower-triangle entries (state after the start-point factorisation is
+    # gone: rebuild without factorising)
+    hip.set_aug_diagonal_reg(st, 1e-8, -1e-8)
+    s.kkt.build_kkt()
+    Kp, ld = hip.kkt_matrix(s.kkt._h, nx)
+    sig = st.pr_diag.cpu().numpy()
+    theta = sig[nx:] / (1.0 - (-1e-8) * sig[nx:])
+    for _ in range(6):
+        j = int(rng.integers(0, nx - 8))
+        i = int(rng.integers(j, nx - 8))
+        got = hip.read_doubles(Kp + 8 * (i + j * ld), 8)  # K[i:i+8, j]
+        Ai, Aj = dq.A[:, i:i + 8].cpu().numpy(), dq.A[:, j].cpu().numpy()
+        ref = dq.H[i:i + 8, j].cpu().numpy() + (Ai * (theta * Aj)[:, None]).sum(axis=0)
+        ref[np.arange(i, i + 8) == j] += sig[j]
+        scale = np.abs(dq.H[i:i + 8, j].cpu().numpy()) + (np.abs(Ai) * (theta * np.abs(Aj))[:, None]).sum(axis=0)
+        assert np.max(np.abs(got - ref) / scale) < 1e-13
+    s.kkt.linear_solver.factorize()
+    assert s.kkt.linear_solver.is_factorized()
+    # (c) two iterations
+    assert s.iteration_head() is None
+    pr0 = s.inf_pr
+    for _ in range(2):
+        s.iteration_body()
+        assert s.last_residual_ratio < 1e-7, s.last_residual_ratio
+        assert s.iteration_head() is None
+    assert s.inf_pr < pr0 and 0 < s.alpha_p <= 1 and 0 < s.alpha_d <= 1
+    s.kkt.close()
