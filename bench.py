@@ -37,6 +37,8 @@ def parse():
     p.add_argument("--m", type=int, default=20000)
     p.add_argument("--max-ncorr", type=int, default=0)
     p.add_argument("--seed", type=int, default=20250614 + 1)
+    p.add_argument("--driver", choices=("native", "python"), default="native",
+                   help="host driver of the loop body: csrc/mpc.hip (one C call per iteration) or solver.py")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-nx", type=int, default=6000)
     p.add_argument("--profile-all", action="store_true", help="time every kernel class (perturbs the "
@@ -168,7 +170,7 @@ def main():
     # options of scripts/benchmarks_cpu.jl:35-44 (kkt_system -> condensed, linear_solver -> HIP Cholesky)
     solver = M.MPCSolver(dq, be, max_iter=300, step_rule=M.AdaptiveStep(0.995),
                          regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12,
-                         max_ncorr=args.max_ncorr, scaling=True)
+                         max_ncorr=args.max_ncorr, scaling=True, driver=args.driver)
     solver.initialize()
     excluded = 0.0  # time of re-initialisations inside the timed region (none unless it converges)
 
@@ -227,7 +229,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"synthetic dense QP nx={nx} m={m} (0<=x<=1, 0<=Ax<=1, Wigner H, Gaussian A), "
                                    f"one independent QP per GPU, max_ncorr={args.max_ncorr}",
-                       "nx": nx, "m": m, "n_slack": m, "max_ncorr": args.max_ncorr,
+                       "nx": nx, "m": m, "n_slack": m, "max_ncorr": args.max_ncorr, "driver": args.driver,
                        "options": "scripts/benchmarks_cpu.jl:35-44 with kkt_system=HIPCondensedKKTSystem, "
                                   "linear_solver=HIPCholeskySolver"},
             "kkt_factor_solve_ms": {
@@ -252,7 +254,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, nx, m)
         print(json.dumps(out), flush=True)
 
-    solver.kkt.close()
+    solver.close()
     be.close()
     if world > 1:
         dist.destroy_process_group()

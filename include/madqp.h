@@ -240,6 +240,43 @@ int32_t madqp_kkt_eval(madqp_kkt* kkt, const madqp_state* st, const double* q, c
 /* device pointer to the assembled / factored K (nx x nx, ld = madqp_kkt_ld) for inspection */
 int32_t madqp_kkt_matrix(madqp_kkt* kkt, double** K, int64_t* ld);
 
+/* ----------------------------------------- native driver of one MPC iteration */
+/* The loop body of mpc! (src/solver.jl:254-345) above the entry points of this header, for hosts
+ * that want one foreign call per iteration (small problems, batches).  The Julia glue does not
+ * need it: MadIPM's own mpc! drives the plugin methods.  Start-up (src/solver.jl:127-182) stays
+ * with the host. */
+typedef struct madqp_mpc madqp_mpc;
+typedef struct madqp_mpc_options { /* src/utils.jl:69-103 */
+    double tol;
+    int64_t max_iter;
+    int32_t max_ncorr;
+    int32_t step_rule;      /* 0 ConservativeStep(tau), 1 AdaptiveStep(tau_min), 2 MehrotraAdaptiveStep(gamma_f) */
+    double step_param;
+    int32_t regularization; /* 0 NoRegularization, 1 FixedRegularization, 2 AdaptiveRegularization */
+    int32_t check_residual;
+    double delta_p, delta_d, delta_min;
+    double mu_min;
+    double tol_linear_solve;
+} madqp_mpc_options;
+typedef struct madqp_mpc_info { /* print_iter tuple (src/structure.jl:178-195) + counters */
+    int64_t k;
+    double obj, inf_pr, inf_du, inf_compl, mu, dnorm, del_w, del_c, alpha_p, alpha_d, residual_ratio;
+    int64_t n_factorizations;
+    int32_t factor_info;
+} madqp_mpc_info;
+/* w1, w2: the _w1/_w2 UnreducedKKTVector buffers (src/structure.jl:36-37); q, rhs, c0: scaled model
+ * data as for madqp_kkt_eval; norm_b, norm_c: src/solver.jl:173-174.  All pointers are borrowed. */
+int32_t madqp_mpc_create(madqp_kkt* kkt, const madqp_state* st, double* w1, double* w2, const double* q,
+                         const double* rhs, double c0, double norm_b, double norm_c,
+                         const madqp_mpc_options* opt, madqp_mpc** out);
+int32_t madqp_mpc_destroy(madqp_mpc* mpc);
+/* scalars produced by the host start-up: mu = mu_init, del_w/del_c of init_regularization!, objective, k */
+int32_t madqp_mpc_set_scalars(madqp_mpc* mpc, double mu, double del_w, double del_c, double obj, int64_t k);
+/* src/solver.jl:259-283; status_host: 0 continue, 1 SOLVE_SUCCEEDED, 6 MAXIMUM_ITERATIONS_EXCEEDED */
+int32_t madqp_mpc_head(madqp_mpc* mpc, madqp_mpc_info* info_host, int32_t* status_host);
+/* src/solver.jl:288-343; returns MADQP_NUM_NAN for MadNLP.SolveException (src/linear_solver.jl:41-43) */
+int32_t madqp_mpc_body(madqp_mpc* mpc, madqp_mpc_info* info_host);
+
 #ifdef __cplusplus
 }
 #endif

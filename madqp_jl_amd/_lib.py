@@ -38,6 +38,24 @@ class CState(C.Structure):
 
 pstate = C.POINTER(CState)
 
+
+class CMpcOptions(C.Structure):
+    """``madqp_mpc_options`` of include/madqp.h."""
+
+    _fields_ = [("tol", f64), ("max_iter", i64), ("max_ncorr", i32), ("step_rule", i32),
+                ("step_param", f64), ("regularization", i32), ("check_residual", i32),
+                ("delta_p", f64), ("delta_d", f64), ("delta_min", f64), ("mu_min", f64),
+                ("tol_linear_solve", f64)]
+
+
+class CMpcInfo(C.Structure):
+    """``madqp_mpc_info`` of include/madqp.h."""
+
+    _fields_ = ([("k", i64)]
+                + [(k, f64) for k in ("obj", "inf_pr", "inf_du", "inf_compl", "mu", "dnorm", "del_w",
+                                      "del_c", "alpha_p", "alpha_d", "residual_ratio")]
+                + [("n_factorizations", i64), ("factor_info", i32)])
+
 # name -> argtypes (every function returns int32 unless listed in _RESTYPE)
 _SIGNATURES = {
     "madqp_version": [],
@@ -98,6 +116,11 @@ _SIGNATURES = {
     "madqp_kkt_jtprod": [vp, vp, vp],
     "madqp_kkt_eval": [vp, pstate, vp, vp, f64, pf64],
     "madqp_kkt_matrix": [vp, C.POINTER(vp), pi64],
+    "madqp_mpc_create": [vp, pstate, vp, vp, vp, vp, f64, f64, f64, C.POINTER(CMpcOptions), C.POINTER(vp)],
+    "madqp_mpc_destroy": [vp],
+    "madqp_mpc_set_scalars": [vp, f64, f64, f64, f64, i64],
+    "madqp_mpc_head": [vp, C.POINTER(CMpcInfo), pi32],
+    "madqp_mpc_body": [vp, C.POINTER(CMpcInfo)],
 }
 _RESTYPE = {"madqp_last_error": C.c_char_p}
 

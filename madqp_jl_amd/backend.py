@@ -308,6 +308,31 @@ class HipBackend:
         self._ck(self.lib.madqp_kkt_eval(h, C.byref(st.cstruct), ptr(q), ptr(rhs), c0, C.byref(obj)))
         return obj.value
 
+    # ---- native driver of one MPC iteration (csrc/mpc.hip) ----
+    def mpc_create(self, kkt_h, st, w1, w2, q, rhs, c0, norm_b, norm_c, copt):
+        h = C.c_void_p()
+        self._ck(self.lib.madqp_mpc_create(kkt_h, C.byref(st.cstruct), ptr(w1), ptr(w2), ptr(q), ptr(rhs),
+                                           c0, norm_b, norm_c, C.byref(copt), C.byref(h)))
+        return h
+
+    def mpc_destroy(self, h):
+        self.lib.madqp_mpc_destroy(h)
+
+    def mpc_set_scalars(self, h, mu, del_w, del_c, obj, k):
+        self._ck(self.lib.madqp_mpc_set_scalars(h, mu, del_w, del_c, obj, k))
+
+    def mpc_head(self, h, info):
+        status = C.c_int32()
+        self._ck(self.lib.madqp_mpc_head(h, C.byref(info), C.byref(status)))
+        return status.value
+
+    def mpc_body(self, h, info) -> int:
+        """Returns the raw status: 0 ok, MADQP_NUM_NAN (>0) = SolveException; <0 raises."""
+        rc = self.lib.madqp_mpc_body(h, C.byref(info))
+        if rc < 0:
+            self._ck(rc)
+        return rc
+
     def kkt_matrix(self, h, nx):
         """Torch view (nx x ld, row = column of K) of the library-owned K for inspection."""
         p, ld = C.c_void_p(), C.c_int64()

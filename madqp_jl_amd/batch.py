@@ -44,7 +44,7 @@ def solve_batch(make_qp, indices, device_index: int = 0, streams: int = 8, **opt
                         break
                     solver = MPCSolver(make_qp(be, i), be, **opts)
                     r = solver.solve()
-                    solver.kkt.close()
+                    solver.close()
                     with lock:
                         results[i] = r
             except Exception as e:  # surfaced to the caller: no silent fallback

@@ -489,6 +489,8 @@ extern "C" int32_t madqp_kkt_eval(madqp_kkt* k, const madqp_state* st, const dou
     return MADQP_OK;
 }
 
+madqp_ctx* madqp_kkt_ctx(madqp_kkt* kkt) { return kkt->ctx; }
+
 extern "C" int32_t madqp_kkt_matrix(madqp_kkt* k, double** K, int64_t* ld) {
     if (!k || !K || !ld) return MADQP_ERR_ARG;
     *K = k->K;

@@ -1,0 +1,332 @@
+// Native host driver of one Mehrotra predictor-corrector iteration (src/solver.jl:259-343).
+//
+// The same control flow as madqp_jl_amd/solver.py (MPCSolver.iteration_head / iteration_body), in
+// C++ above the kernels of this library: one foreign call per iteration instead of ~60, so the host
+// overhead of an interpreted driver disappears (it matters for small problems and for batches,
+// where each host thread drives its own context).  Scalars still come back per reduction; the
+// fully device-resident variant is listed as next in DESIGN.md.
+#include <cmath>
+
+#include "common.h"
+
+struct madqp_mpc {
+    madqp_kkt* kkt;
+    madqp_ctx* ctx;
+    madqp_state st;
+    double *w1, *w2;
+    const double *q, *rhs;
+    double c0, norm_b, norm_c;
+    madqp_mpc_options opt;
+    // mutable solver scalars (src/structure.jl:60-75)
+    double mu, del_w, del_c, alpha_p, alpha_d, obj, inf_pr, inf_du, inf_compl, dnorm, residual_ratio;
+    double reg_delta_p, reg_delta_d;  // AdaptiveRegularization state (src/kernels.jl:410-417)
+    int64_t k, n_factorizations;
+    int32_t last_info;
+};
+
+madqp_ctx* madqp_kkt_ctx(madqp_kkt* kkt);  // kkt.hip
+
+namespace {
+#define TRY(expr)               \
+    do {                        \
+        int32_t r_ = (expr);    \
+        if (r_) return r_;      \
+    } while (0)
+
+int64_t ntot(const madqp_state& s) { return s.n + s.m + s.nlb + s.nub; }
+
+// src/kernels.jl:386-417
+void update_regularization(madqp_mpc* s) {
+    switch (s->opt.regularization) {
+        case 0:
+            s->del_w = 0.0;
+            s->del_c = 0.0;
+            break;
+        case 1:
+            s->del_w = s->opt.delta_p;
+            s->del_c = s->opt.delta_d;
+            break;
+        default:
+            s->reg_delta_p = std::max(s->reg_delta_p / 10.0, s->opt.delta_min);
+            s->reg_delta_d = std::min(s->reg_delta_d / 10.0, -s->opt.delta_min);
+            s->del_w = s->reg_delta_p;
+            s->del_c = s->reg_delta_d;
+    }
+}
+
+// src/linear_solver.jl:6-17
+int32_t factorize_regularized_system(madqp_mpc* s) {
+    for (int trial = 0; trial < 3; ++trial) {
+        TRY(madqp_set_aug_diagonal_reg(s->ctx, &s->st, s->del_w, s->del_c));
+        TRY(madqp_kkt_build(s->kkt, &s->st));
+        TRY(madqp_kkt_factorize(s->kkt, &s->last_info));
+        s->n_factorizations += 1;
+        if (s->last_info == 0) break;
+        s->del_w *= 100.0;
+        s->del_c *= 100.0;
+    }
+    return MADQP_OK;
+}
+
+// src/linear_solver.jl:19-45
+int32_t solve_system(madqp_mpc* s) {
+    const int64_t len = ntot(s->st);
+    TRY(madqp_copy(s->ctx, len, s->st.p, s->st.d));
+    TRY(madqp_kkt_solve(s->kkt, &s->st, s->st.d));
+    TRY(madqp_copy(s->ctx, len, s->st.p, s->w1));
+    TRY(madqp_kkt_mul(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));
+    double nrm[3];
+    TRY(madqp_norm_inf3(s->ctx, len, s->w1, s->st.p, s->st.d, nrm));
+    const double ratio = nrm[0] / std::max(1.0, nrm[1]);
+    s->residual_ratio = ratio;
+    if (std::isnan(ratio) || (s->opt.check_residual && ratio > s->opt.tol_linear_solve))
+        return MADQP_NUM_NAN;  // MadNLP.SolveException
+    return MADQP_OK;
+}
+
+// src/kernels.jl:290-305
+int32_t fraction_to_boundary(madqp_mpc* s, double tau, double* ap, double* ad, double* a4 = nullptr,
+                             int64_t* i4 = nullptr) {
+    double a[4];
+    int64_t ib[4];
+    TRY(madqp_get_alpha_max(s->ctx, &s->st, tau, a, ib));
+    *ap = std::min(a[0], a[1]);
+    *ad = std::min(a[2], a[3]);
+    if (a4)
+        for (int q = 0; q < 4; ++q) {
+            a4[q] = a[q];
+            i4[q] = ib[q];
+        }
+    return MADQP_OK;
+}
+
+int32_t read1(madqp_mpc* s, const double* dptr, double* out) {
+    return madqp_memcpy_d2h(s->ctx, out, dptr, sizeof(double));
+}
+int32_t read_idx(madqp_mpc* s, const int64_t* dptr, int64_t* out) {
+    return madqp_memcpy_d2h(s->ctx, out, dptr, sizeof(int64_t));
+}
+
+// update_step!(::MehrotraAdaptiveStep), src/kernels.jl:325-374 (scalar reads at the blocking indices)
+int32_t mehrotra_adaptive_step(madqp_mpc* s) {
+    const madqp_state& st = s->st;
+    const double gamma_f = s->opt.step_param, gamma_a = 1.0 / (1.0 - gamma_f);
+    double a[4], max_ap, max_ad;
+    int64_t ib[4];
+    TRY(fraction_to_boundary(s, 1.0, &max_ap, &max_ad, a, ib));
+    double mu_full;
+    TRY(madqp_get_affine_complementarity_measure(s->ctx, &s->st, max_ap, max_ad, &mu_full));
+    mu_full /= gamma_a;
+    const double* dx = st.d;
+    const double* dzl = st.d + st.n + st.m;
+    const double* dzu = dzl + st.nlb;
+    double alpha_p = 1.0, alpha_d = 1.0;
+    auto at_lb = [&](const double* vec, int64_t i, double* out) {
+        int64_t j;
+        int32_t r = read_idx(s, st.ind_lb + i, &j);
+        return r ? r : read1(s, vec + j, out);
+    };
+    auto at_ub = [&](const double* vec, int64_t i, double* out) {
+        int64_t j;
+        int32_t r = read_idx(s, st.ind_ub + i, &j);
+        return r ? r : read1(s, vec + j, out);
+    };
+    if (max_ap < 1.0) {
+        double z, dz, x, b, d;
+        if (a[0] <= a[1]) {
+            const int64_t i = ib[0];
+            TRY(at_lb(st.zl, i, &z));
+            TRY(read1(s, dzl + i, &dz));
+            TRY(at_lb(st.x, i, &x));
+            TRY(at_lb(st.xl, i, &b));
+            TRY(at_lb(dx, i, &d));
+            const double tmp = mu_full / (z + max_ad * dz);
+            alpha_p = (x - b - tmp) / (-d);
+        } else {
+            const int64_t i = ib[1];
+            TRY(at_ub(st.zu, i, &z));
+            TRY(read1(s, dzu + i, &dz));
+            TRY(at_ub(st.x, i, &x));
+            TRY(at_ub(st.xu, i, &b));
+            TRY(at_ub(dx, i, &d));
+            const double tmp = mu_full / (z + max_ad * dz);
+            alpha_p = (b - x - tmp) / d;
+        }
+    }
+    if (max_ad < 1.0) {
+        double z, dz, x, b, d;
+        if (a[2] <= a[3]) {
+            const int64_t i = ib[2];
+            TRY(at_lb(st.x, i, &x));
+            TRY(at_lb(dx, i, &d));
+            TRY(at_lb(st.xl, i, &b));
+            TRY(at_lb(st.zl, i, &z));
+            TRY(read1(s, dzl + i, &dz));
+            const double tmp = mu_full / (x + max_ap * d - b);
+            alpha_d = -(z - tmp) / dz;
+        } else {
+            const int64_t i = ib[3];
+            TRY(at_ub(st.x, i, &x));
+            TRY(at_ub(dx, i, &d));
+            TRY(at_ub(st.xu, i, &b));
+            TRY(at_ub(st.zu, i, &z));
+            TRY(read1(s, dzu + i, &dz));
+            const double tmp = mu_full / (b - x - max_ap * d);
+            alpha_d = -(z - tmp) / dz;
+        }
+    }
+    s->alpha_p = std::max(alpha_p, gamma_f * max_ap);
+    s->alpha_d = std::max(alpha_d, gamma_f * max_ad);
+    return MADQP_OK;
+}
+
+// src/solver.jl:200-251
+int32_t gondzio(madqp_mpc* s, double mu_curr) {
+    const double delta = 0.1, bmin = 0.1, bmax = 10.0, tau = 0.995;
+    const int64_t len = ntot(s->st);
+    double alpha_p, alpha_d;
+    TRY(fraction_to_boundary(s, tau, &alpha_p, &alpha_d));
+    for (int c = 0; c < s->opt.max_ncorr; ++c) {
+        const double ta_p = std::min(alpha_p + delta, 1.0), ta_d = std::min(alpha_d + delta, 1.0);
+        double ga;
+        TRY(madqp_get_affine_complementarity_measure(s->ctx, &s->st, ta_p, ta_d, &ga));
+        const double mu = (ga / mu_curr) * (ga / mu_curr) * ga;
+        TRY(madqp_set_extra_correction(s->ctx, &s->st, ta_p, ta_d, bmin, bmax, mu));
+        TRY(madqp_set_correction_rhs(s->ctx, &s->st, mu));
+        TRY(madqp_copy(s->ctx, len, s->st.d, s->w2));
+        TRY(solve_system(s));
+        double ha_p, ha_d;
+        TRY(fraction_to_boundary(s, tau, &ha_p, &ha_d));
+        if (ha_p < 1.005 * alpha_p || ha_d < 1.005 * alpha_d) {
+            TRY(madqp_copy(s->ctx, len, s->w2, s->st.d));
+            break;
+        }
+        alpha_p = ha_p;
+        alpha_d = ha_d;
+    }
+    return MADQP_OK;
+}
+
+void fill_info(const madqp_mpc* s, madqp_mpc_info* i) {
+    if (!i) return;
+    i->k = s->k;
+    i->obj = s->obj;
+    i->inf_pr = s->inf_pr;
+    i->inf_du = s->inf_du;
+    i->inf_compl = s->inf_compl;
+    i->mu = s->mu;
+    i->dnorm = s->dnorm;
+    i->del_w = s->del_w;
+    i->del_c = s->del_c;
+    i->alpha_p = s->alpha_p;
+    i->alpha_d = s->alpha_d;
+    i->residual_ratio = s->residual_ratio;
+    i->n_factorizations = s->n_factorizations;
+    i->factor_info = s->last_info;
+}
+}  // namespace
+
+extern "C" int32_t madqp_mpc_create(madqp_kkt* kkt, const madqp_state* st, double* w1, double* w2,
+                                    const double* q, const double* rhs, double c0, double norm_b,
+                                    double norm_c, const madqp_mpc_options* opt, madqp_mpc** out) {
+    if (!kkt || !out) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = madqp_kkt_ctx(kkt);
+    ARG_TRY(ctx, st && opt && (ntot(*st) == 0 || (w1 && w2)));
+    ARG_TRY(ctx, opt->step_rule >= 0 && opt->step_rule <= 2 && opt->regularization >= 0 &&
+                     opt->regularization <= 2 && opt->max_ncorr >= 0);
+    madqp_mpc* s = new (std::nothrow) madqp_mpc();
+    if (!s) return madqp_fail(ctx, MADQP_ERR_ALLOC, "host allocation failed");
+    memset(s, 0, sizeof(*s));
+    s->kkt = kkt;
+    s->ctx = ctx;
+    s->st = *st;
+    s->w1 = w1;
+    s->w2 = w2;
+    s->q = q;
+    s->rhs = rhs;
+    s->c0 = c0;
+    s->norm_b = norm_b;
+    s->norm_c = norm_c;
+    s->opt = *opt;
+    s->reg_delta_p = opt->delta_p;
+    s->reg_delta_d = opt->delta_d;
+    *out = s;
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_mpc_destroy(madqp_mpc* s) {
+    delete s;
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_mpc_set_scalars(madqp_mpc* s, double mu, double del_w, double del_c, double obj,
+                                         int64_t k) {
+    if (!s) return MADQP_ERR_ARG;
+    s->mu = mu;
+    s->del_w = del_w;
+    s->del_c = del_c;
+    s->obj = obj;
+    s->k = k;
+    return MADQP_OK;
+}
+
+// src/solver.jl:259-283: residuals and the termination test.
+// status_host: 0 = continue, 1 = SOLVE_SUCCEEDED, 6 = MAXIMUM_ITERATIONS_EXCEEDED
+extern "C" int32_t madqp_mpc_head(madqp_mpc* s, madqp_mpc_info* info_host, int32_t* status_host) {
+    if (!s || !status_host) return MADQP_ERR_ARG;
+    TRY(madqp_kkt_jtprod(s->kkt, s->st.jacl, s->st.y));
+    double nrm[3];
+    TRY(madqp_get_inf(s->ctx, &s->st, nrm));
+    s->inf_pr = nrm[0] / std::max(1.0, s->norm_b);
+    s->inf_du = nrm[1] / std::max(1.0, s->norm_c);
+    s->inf_compl = nrm[2] / std::max(1.0, s->norm_c);
+    fill_info(s, info_host);
+    if (std::max(s->inf_pr, std::max(s->inf_du, s->inf_compl)) <= s->opt.tol)
+        *status_host = 1;
+    else if (s->k >= s->opt.max_iter)
+        *status_host = 6;
+    else
+        *status_host = 0;
+    return MADQP_OK;
+}
+
+// src/solver.jl:288-343: one predictor-corrector step.  Returns MADQP_NUM_NAN for the
+// SolveException of src/linear_solver.jl:41-43.
+extern "C" int32_t madqp_mpc_body(madqp_mpc* s, madqp_mpc_info* info_host) {
+    if (!s) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = s->ctx;
+    update_regularization(s);                   // :288
+    TRY(factorize_regularized_system(s));       // :289
+    TRY(madqp_set_predictive_rhs(ctx, &s->st)); // :294
+    TRY(solve_system(s));
+    double a_aff_p, a_aff_d, mu_affine, mu_curr;
+    TRY(fraction_to_boundary(s, 1.0, &a_aff_p, &a_aff_d));  // :295
+    TRY(madqp_get_affine_complementarity_measure(ctx, &s->st, a_aff_p, a_aff_d, &mu_affine));  // :296
+    TRY(madqp_get_correction(ctx, &s->st));     // :297
+    // update_barrier!(Mehrotra), src/kernels.jl:226-236 (field-order quirk: "any bound")
+    TRY(madqp_get_complementarity_measure(ctx, &s->st, &mu_curr));
+    double sigma = 1.0;
+    if (s->st.nlb + s->st.nub > 0) {
+        const double t = mu_affine / mu_curr;
+        sigma = std::min(std::max(std::pow(t, 3.0), 1e-6), 10.0);  // pow: same libm call as the Python driver
+    }
+    s->mu = std::max(s->opt.mu_min, sigma * mu_curr);
+    TRY(madqp_set_correction_rhs(ctx, &s->st, s->mu));  // :307
+    TRY(solve_system(s));
+    if (s->opt.max_ncorr > 0) TRY(gondzio(s, mu_curr));  // :316-324
+    // update_step!, src/kernels.jl:307-374
+    if (s->opt.step_rule == 0) {
+        TRY(fraction_to_boundary(s, s->opt.step_param, &s->alpha_p, &s->alpha_d));
+    } else if (s->opt.step_rule == 1) {
+        TRY(fraction_to_boundary(s, std::max(1.0 - s->mu, s->opt.step_param), &s->alpha_p, &s->alpha_d));
+    } else {
+        TRY(mehrotra_adaptive_step(s));
+    }
+    TRY(madqp_norm_inf(ctx, s->st.n, s->st.d, &s->dnorm));             // print_iter, src/structure.jl:190
+    TRY(madqp_update_iterates(ctx, &s->st, s->alpha_p, s->alpha_d));   // :332-335
+    TRY(madqp_kkt_eval(s->kkt, &s->st, s->q, s->rhs, s->c0, &s->obj)); // :338-340
+    TRY(madqp_adjust_boundary(ctx, &s->st, s->mu));                    // :342
+    s->k += 1;
+    fill_info(s, info_host);
+    return MADQP_OK;
+}

@@ -17,6 +17,7 @@ import math
 import numpy as np
 import torch
 
+from ._lib import CMpcInfo, CMpcOptions
 from .kkt import HIPCondensedKKTSystem, HIPNormalKKTSystem
 from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, FixedRegularization,
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
@@ -94,6 +95,54 @@ class MPCSolver:
         self.trace = []
         self.last_residual_ratio = 0.0
         self.dnorm = 0.0
+        if self.opt.driver not in ("python", "native"):
+            raise ValueError(f"unknown driver {self.opt.driver!r}")
+        self._native = None  # madqp_mpc handle (driver="native")
+        self._info = CMpcInfo()
+
+    # ---- driver="native": the loop body runs in csrc/mpc.hip, one foreign call per iteration ----
+    def _native_options(self) -> CMpcOptions:
+        opt, rule, reg = self.opt, self.opt.step_rule, self.opt.regularization
+        c = CMpcOptions(tol=opt.tol, max_iter=opt.max_iter, max_ncorr=opt.max_ncorr, mu_min=opt.mu_min,
+                        check_residual=int(bool(opt.check_residual)),
+                        tol_linear_solve=opt.tol_linear_solve)
+        if isinstance(rule, ConservativeStep):
+            c.step_rule, c.step_param = 0, rule.tau
+        elif isinstance(rule, AdaptiveStep):
+            c.step_rule, c.step_param = 1, rule.tau_min
+        elif isinstance(rule, MehrotraAdaptiveStep):
+            c.step_rule, c.step_param = 2, rule.gamma_f
+        else:
+            raise TypeError(rule)
+        if isinstance(reg, NoRegularization):
+            c.regularization = 0
+        elif isinstance(reg, FixedRegularization):
+            c.regularization, c.delta_p, c.delta_d = 1, reg.delta_p, reg.delta_d
+        else:
+            c.regularization, c.delta_p, c.delta_d, c.delta_min = 2, reg.delta_p, reg.delta_d, reg.delta_min
+        return c
+
+    def _native_open(self):
+        self._native_close()
+        st = self.st
+        self._native = self.be.mpc_create(self.kkt._h, st, st.w1, st.w2, self.q, st.rhs,
+                                          self.obj_scale * self.qp.c0, self.norm_b, self.norm_c,
+                                          self._native_options())
+        self.be.mpc_set_scalars(self._native, self.mu, self.del_w, self.del_c, self.obj_val, self.k)
+
+    def _native_close(self):
+        if self._native is not None:
+            self.be.mpc_destroy(self._native)
+            self._native = None
+
+    def _native_pull(self):
+        i = self._info
+        self.k, self.obj_val, self.mu, self.dnorm = i.k, i.obj, i.mu, i.dnorm
+        self.inf_pr, self.inf_du, self.inf_compl = i.inf_pr, i.inf_du, i.inf_compl
+        self.del_w, self.del_c, self.alpha_p, self.alpha_d = i.del_w, i.del_c, i.alpha_p, i.alpha_d
+        self.last_residual_ratio = i.residual_ratio
+        self.kkt.n_factorizations = self._n_fact0 + i.n_factorizations
+        self.kkt.linear_solver.info = i.factor_info
 
     # ---- src/kernels.jl:380-417 (host scalars) ----
     def init_regularization(self):
@@ -288,6 +337,9 @@ class MPCSolver:
         self.mu = opt.mu_init  # :179
         self.k = 0
         self.trace = []
+        if opt.driver == "native":
+            self._n_fact0 = self.kkt.n_factorizations
+            self._native_open()
 
     def affine_direction(self):  # :188-192
         self.be.set_predictive_rhs(self.st)
@@ -329,6 +381,11 @@ class MPCSolver:
 
     def iteration_head(self):
         """src/solver.jl:259-283: residuals and the termination test."""
+        if self._native is not None:
+            status = self.be.mpc_head(self._native, self._info)
+            self._native_pull()
+            self.record()
+            return status or None
         st = self.st
         self.kkt.jtprod(st.jacl, st.y)  # :259
         nc, nd, ncompl = self.be.get_inf(st)
@@ -344,6 +401,12 @@ class MPCSolver:
 
     def iteration_body(self):
         """src/solver.jl:288-343: one predictor-corrector step (the timed unit of bench.py)."""
+        if self._native is not None:
+            rc = self.be.mpc_body(self._native, self._info)
+            if rc != 0:
+                raise SolveException()
+            self._native_pull()
+            return
         st, be = self.st, self.be
         self.update_regularization()  # :288
         self.factorize_regularized_system()  # :289
@@ -382,6 +445,12 @@ class MPCSolver:
             if self.opt.rethrow_error:
                 raise
         return self.result()
+
+    def close(self):
+        """Release the library objects (native driver, KKT system)."""
+        self._native_close()
+        if self.kkt is not None:
+            self.kkt.close()
 
     def result(self):
         """MadNLP.update!(stats, solver): unscaled solution / objective / multipliers."""

@@ -29,8 +29,11 @@ def solve_hip(qp, be, **opts):
     opts.setdefault("regularization", M.FixedRegularization(1e-8, -1e-8))
     s = M.MPCSolver(to_device(qp, be), be, **opts)
     r = s.solve()
-    s.kkt.close()
+    s.close()
     return r
+
+
+DRIVERS = pytest.mark.parametrize("driver", ["python", "native"])
 
 
 def close(a, b, tol):
@@ -58,10 +61,11 @@ CASES = {
 NCORR = {"dummy_20_15_eq_gondzio": 5, "synthetic_40_16_gondzio": 3}
 
 
+@DRIVERS
 @pytest.mark.parametrize("name", list(CASES))
-def test_golden_traces(hip, name):
+def test_golden_traces(hip, name, driver):
     g = GOLDEN[name]
-    r = solve_hip(CASES[name](), hip, max_ncorr=NCORR.get(name, 0))
+    r = solve_hip(CASES[name](), hip, max_ncorr=NCORR.get(name, 0), driver=driver)
     assert r["status"] == g["status"] == M.SOLVE_SUCCEEDED
     assert r["iter"] == g["iter"]
     compare_traces(r["trace"], g["trace"], name)
@@ -82,12 +86,13 @@ def test_known_answers(hip):
         M.MPCSolver(to_device(Q.simple_lp(), hip), hip)  # default delta_d = 0 with an equality row
 
 
+@DRIVERS
 @pytest.mark.parametrize("n,m,ncorr", [(300, 120, 0), (300, 120, 3), (1500, 600, 0)])
-def test_synthetic_vs_oracle(hip, n, m, ncorr):
+def test_synthetic_vs_oracle(hip, n, m, ncorr, driver):
     qp = Q.synthetic_qp(20250614 + n, n, m)
     ref = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8),
                     max_ncorr=ncorr)
-    r = solve_hip(qp, hip, max_ncorr=ncorr)
+    r = solve_hip(qp, hip, max_ncorr=ncorr, driver=driver)
     assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
     compare_traces(r["trace"], ref["trace"], f"synthetic {n}x{m}")
     assert close(r["objective"], ref["objective"], 1e-9)
@@ -95,27 +100,30 @@ def test_synthetic_vs_oracle(hip, n, m, ncorr):
     assert np.max(np.abs(r["multipliers"] - ref["multipliers"])) <= 1e-6
 
 
+@DRIVERS
 @pytest.mark.parametrize("rule", ["adaptive", "conservative", "mehrotra"])
-def test_step_rules(hip, rule):
+def test_step_rules(hip, rule, driver):
     """test/runtests.jl:80-92: every step rule reaches SOLVE_SUCCEEDED; here also == oracle."""
     mk = {"adaptive": (M.AdaptiveStep(0.99), mpc.AdaptiveStep(0.99)),
           "conservative": (M.ConservativeStep(0.99), mpc.ConservativeStep(0.99)),
           "mehrotra": (M.MehrotraAdaptiveStep(0.99), mpc.MehrotraAdaptiveStep(0.99))}[rule]
     qp = Q.dummy_qp(10, 5)
-    r = solve_hip(qp, hip, step_rule=mk[0])
+    r = solve_hip(qp, hip, step_rule=mk[0], driver=driver)
     ref = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8),
                     step_rule=mk[1])
     assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
     compare_traces(r["trace"], ref["trace"], rule)
 
 
+@DRIVERS
 @pytest.mark.parametrize("reg", ["fixed", "adaptive"])
-def test_regularizations(hip, reg):
+def test_regularizations(hip, reg, driver):
     """test/runtests.jl:117-135: regularized runs match the reference solution to 1e-6."""
     qp = Q.dummy_qp(10, 5)
     sol_ref = mpc.solve(qp, kkt_system="K2", regularization=mpc.NoRegularization())
     r = solve_hip(qp, hip, regularization=(M.FixedRegularization(1e-8, -1e-9) if reg == "fixed"
-                                           else M.AdaptiveRegularization(1e-8, -1e-9, 1e-9)))
+                                           else M.AdaptiveRegularization(1e-8, -1e-9, 1e-9)),
+                  driver=driver)
     assert r["status"] == M.SOLVE_SUCCEEDED
     assert abs(r["objective"] - sol_ref["objective"]) < 1e-6
     assert np.max(np.abs(r["solution"] - sol_ref["solution"])) < 1e-6
@@ -190,14 +198,15 @@ def test_full_size_properties_n5k(hip):
     s.kkt.close()
 
 
+@DRIVERS
 @pytest.mark.parametrize("case", ["simple_lp", "lp_30_12", "lp_400_150"])
-def test_normal_kkt_system(hip, case):
+def test_normal_kkt_system(hip, case, driver):
     """The reference's own NormalKKTSystem formulation on the device (kkt_system="normal"), with the
     reference's default regularization (delta_d = 0) and equality rows: test/runtests.jl:165-180."""
     qp = {"simple_lp": Q.simple_lp, "lp_30_12": lambda: Q.synthetic_qp(20250615, 30, 12, "lp"),
           "lp_400_150": lambda: Q.synthetic_qp(5, 400, 150, "lp")}[case]()
     reg, oreg = M.FixedRegularization(1e-8, 0.0), mpc.FixedRegularization(1e-8, 0.0)
-    r = solve_hip(qp, hip, kkt_system="normal", regularization=reg)
+    r = solve_hip(qp, hip, kkt_system="normal", regularization=reg, driver=driver)
     ref = mpc.solve(qp, kkt_system="normal", regularization=oreg)
     assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
     compare_traces(r["trace"], ref["trace"], f"normal {case}")
@@ -229,6 +238,27 @@ def test_normal_kkt_conformance(hip):
     s.kkt.mul(st.w1, st.d, 1.0, 0.0)
     assert np.max(np.abs(st.w1.cpu().numpy() - b)) / max(1.0, np.max(np.abs(b))) < 1e-9
     s.kkt.close()
+
+
+def test_native_driver_is_bitwise_the_python_driver(hip):
+    """csrc/mpc.hip issues the same kernels in the same order as solver.py: identical traces, bit for bit
+    (Gondzio corrections and the Mehrotra step rule included), and a NaN surfaces as the same status."""
+    for qp, kw in ((Q.synthetic_qp(77, 200, 80), dict(max_ncorr=3)),
+                   (Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)), dict(step_rule=M.MehrotraAdaptiveStep(0.99))),
+                   (Q.synthetic_qp(78, 120, 50, "lp"), dict(regularization=M.AdaptiveRegularization(1e-8, -1e-9, 1e-9)))):
+        a = solve_hip(qp, hip, driver="python", **kw)
+        b = solve_hip(qp, hip, driver="native", **kw)
+        assert a["status"] == b["status"] == M.SOLVE_SUCCEEDED and a["iter"] == b["iter"]
+        assert a["trace"] == b["trace"] and a["n_factorizations"] == b["n_factorizations"]
+        assert np.array_equal(a["solution"], b["solution"]) and a["objective"] == b["objective"]
+    for driver in ("python", "native"):  # NaN inside the loop -> SolveException -> ERROR_IN_STEP_COMPUTATION
+        s = M.MPCSolver(to_device(Q.synthetic_qp(79, 60, 20), hip), hip, driver=driver,
+                        regularization=M.FixedRegularization(1e-8, -1e-8))
+        s.initialize()
+        s.st.x[3] = float("nan")
+        with pytest.raises(M.SolveException):
+            s.mpc()
+        s.close()
 
 
 def test_batch_of_independent_qps(hip):

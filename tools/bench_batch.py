@@ -24,6 +24,7 @@ def main():
     p.add_argument("--m", type=int, default=256)
     p.add_argument("--streams", type=int, default=16)
     p.add_argument("--seed", type=int, default=20250614 + 3)
+    p.add_argument("--driver", choices=("native", "python"), default="native")
     a = p.parse_args()
     import torch
 
@@ -33,7 +34,7 @@ def main():
     mine = M.shard(range(a.batch), rank, world)
     make = lambda be, i: M.DeviceQP.synthetic(be, a.seed + i, a.nx, a.m)
     opts = dict(max_iter=300, step_rule=M.AdaptiveStep(0.995), regularization=M.FixedRegularization(1e-8, -1e-8),
-                mu_min=1e-12)
+                mu_min=1e-12, driver=a.driver)
     M.solve_batch(make, mine[: min(len(mine), a.streams)], local_rank, a.streams, **opts)  # warm-up
     bench.dist_barrier(world)
     t0 = time.perf_counter()
@@ -52,7 +53,7 @@ def main():
         print(json.dumps({"metric": "independent QPs solved per second", "value": a.batch / dt, "unit": "QP/s",
                           "ipm_iterations_per_s": iters / dt, "n_gpus": world, "batch": a.batch,
                           "solved": ok, "config": {"workload": f"{a.batch} x synthetic dense QP nx={a.nx} m={a.m}",
-                                                   "streams_per_gpu": a.streams}, "seconds": dt}), flush=True)
+                                                   "streams_per_gpu": a.streams, "driver": a.driver}, "seconds": dt}), flush=True)
 
 
 if __name__ == "__main__":
