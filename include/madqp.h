@@ -240,6 +240,35 @@ int32_t madqp_kkt_eval(madqp_kkt* kkt, const madqp_state* st, const double* q, c
 /* device pointer to the assembled / factored K (nx x nx, ld = madqp_kkt_ld) for inspection */
 int32_t madqp_kkt_matrix(madqp_kkt* kkt, double** K, int64_t* ld);
 
+/* ----------------------------------------- multi-GPU factorisation pieces */
+/* One dense KKT over several GPUs, one process per GPU: block columns ("panels", starts and widths
+ * multiples of 128, the last one may be short) are dealt round-robin to the ranks.  A rank assembles
+ * and factors the panels it owns; a finished panel travels once to every other rank as a packed
+ * image (the host broadcasts the buffer with RCCL), is unpacked into the local copy of L and applied
+ * to the panels the receiver owns.  Afterwards every rank holds the whole factor, so
+ * madqp_chol_solve / madqp_kkt_solve need no communication.  All calls are asynchronous on the
+ * context's stream except factor_end.  Orchestration: madqp_jl_amd/dist.py. */
+/* madqp_syrk_assemble for the column ranges [ranges_host[2r], ranges_host[2r+1]) only (rows >= start) */
+int32_t madqp_syrk_assemble_cols(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B, int64_t ldb,
+                                 const double* w, const double* base, int64_t ldbase, const double* dvec,
+                                 double* C, int64_t ldc, int64_t nranges, const int64_t* ranges_host);
+/* build_kkt! (src/KKT/normalkkt.jl:166-180) restricted to those block columns of K */
+int32_t madqp_kkt_build_cols(madqp_kkt* kkt, const madqp_state* st, int64_t nranges, const int64_t* ranges_host);
+/* the linear solver object of a KKT system and the order of its matrix (borrowed handle) */
+int32_t madqp_kkt_chol(madqp_kkt* kkt, madqp_chol** chol, int64_t* order);
+/* start a factorisation of the column-major lower matrix A (clears info) */
+int32_t madqp_chol_factor_begin(madqp_chol* s, double* A, int64_t lda);
+/* factor columns [j0, j0+w), which already carry the updates of all columns < j0 (all rows below too) */
+int32_t madqp_chol_factor_panel(madqp_chol* s, int64_t j0, int64_t w);
+/* A[c0:n, c0:c0+cw] -= L[c0:n, p0:p0+pw] L[c0:c0+cw, p0:p0+pw]'  (lower part; p0+pw <= c0) */
+int32_t madqp_chol_update_cols(madqp_chol* s, int64_t c0, int64_t cw, int64_t p0, int64_t pw);
+/* packed image of a factored panel: [info, 0 | inverse diagonal blocks | L[j0:n, j0:j0+w]] */
+int32_t madqp_chol_panel_doubles(madqp_chol* s, int64_t j0, int64_t w, int64_t* count_host);
+int32_t madqp_chol_panel_pack(madqp_chol* s, int64_t j0, int64_t w, double* buf);
+int32_t madqp_chol_panel_unpack(madqp_chol* s, int64_t j0, int64_t w, const double* buf);
+/* info as madqp_chol_factor (first failing column over all ranks: it travels in the packed image) */
+int32_t madqp_chol_factor_end(madqp_chol* s, int32_t* info_host);
+
 /* ----------------------------------------- native driver of one MPC iteration */
 /* The loop body of mpc! (src/solver.jl:254-345) above the entry points of this header, for hosts
  * that want one foreign call per iteration (small problems, batches).  The Julia glue does not

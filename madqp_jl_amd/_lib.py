@@ -116,6 +116,16 @@ _SIGNATURES = {
     "madqp_kkt_jtprod": [vp, vp, vp],
     "madqp_kkt_eval": [vp, pstate, vp, vp, f64, pf64],
     "madqp_kkt_matrix": [vp, C.POINTER(vp), pi64],
+    "madqp_syrk_assemble_cols": [vp, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, i64, pi64],
+    "madqp_kkt_build_cols": [vp, pstate, i64, pi64],
+    "madqp_kkt_chol": [vp, C.POINTER(vp), pi64],
+    "madqp_chol_factor_begin": [vp, vp, i64],
+    "madqp_chol_factor_panel": [vp, i64, i64],
+    "madqp_chol_update_cols": [vp, i64, i64, i64, i64],
+    "madqp_chol_panel_doubles": [vp, i64, i64, pi64],
+    "madqp_chol_panel_pack": [vp, i64, i64, vp],
+    "madqp_chol_panel_unpack": [vp, i64, i64, vp],
+    "madqp_chol_factor_end": [vp, pi32],
     "madqp_mpc_create": [vp, pstate, vp, vp, vp, vp, f64, f64, f64, C.POINTER(CMpcOptions), C.POINTER(vp)],
     "madqp_mpc_destroy": [vp],
     "madqp_mpc_set_scalars": [vp, f64, f64, f64, f64, i64],

@@ -377,8 +377,10 @@ static int64_t outer_panel_width(int64_t rows, bool has_update, int64_t slots) {
 }
 
 static int32_t panel_update(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t row0,
-                            int64_t k0, int64_t width) {
-    // C[row0:n, row0:row0+width] -= L[row0:n, k0:row0] * L[row0:row0+width, k0:row0]'
+                            int64_t k0, int64_t width, int64_t kend = -1) {
+    // C[row0:n, row0:row0+width] -= L[row0:n, k0:kend] * L[row0:row0+width, k0:kend]'   (kend = row0
+    // unless given: the distributed factorisation applies one received panel at a time)
+    if (kend < 0) kend = row0;
     GemmArgs g{};
     g.X = A + row0 + k0 * lda;
     g.ldx = lda;
@@ -392,7 +394,7 @@ static int32_t panel_update(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, i
     g.beta = 1.0;
     g.M = n - row0;
     g.N = width;
-    g.K = row0 - k0;
+    g.K = kend - k0;
     // rows up to the padded order may be read when the leading dimension covers them (the KKT
     // object allocates K that way): no partial tiles, stores stay masked to M x N
     const int64_t npad = (n + NB - 1) / NB * NB;
@@ -478,6 +480,104 @@ extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int3
         int32_t r = factor_range(s, A, lda, J0, W);
         if (r) return r;
     }
+    int32_t info = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&info, s->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *info_host = info;
+    s->factored = (info == 0);
+    return MADQP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pieces of the factorisation for the multi-GPU path (madqp_jl_amd/dist.py): block
+// columns ("panels", width a multiple of 128) are dealt round-robin to the ranks; a rank factors a
+// panel it owns once every panel to its left has been applied to it, packs it, the host broadcasts
+// the packed image (RCCL), the other ranks unpack it into their copy of L and apply it to the
+// panels they own.  All calls are asynchronous on the context's stream; only factor_end reads back.
+namespace {
+__global__ void info_store_kernel(const int32_t* __restrict__ info, double* __restrict__ hdr) {
+    hdr[0] = (double)*info;
+    hdr[1] = 0.0;
+}
+__global__ void info_merge_kernel(int32_t* __restrict__ info, const double* __restrict__ hdr) {
+    const int32_t in = (int32_t)hdr[0];
+    if (in != 0) atomicCAS(info, 0, in);  // keep the first failing column, as on one GPU
+}
+constexpr int64_t PACK_HDR = 2;  // doubles: [info, 0] (keeps the payload 16-byte aligned)
+
+bool panel_ok(const madqp_chol* s, int64_t j0, int64_t w) {
+    return s->A && j0 >= 0 && w > 0 && j0 % NB == 0 && j0 + w <= s->n && (w % NB == 0 || j0 + w == s->n);
+}
+}  // namespace
+
+extern "C" int32_t madqp_chol_factor_begin(madqp_chol* s, double* A, int64_t lda) {
+    if (!s) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, A && lda >= s->n);
+    s->factored = false;
+    s->A = A;
+    s->lda = lda;
+    HIP_TRY(ctx, hipMemsetAsync(s->d_info, 0, sizeof(int32_t), ctx->stream));
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_chol_factor_panel(madqp_chol* s, int64_t j0, int64_t w) {
+    if (!s) return MADQP_ERR_ARG;
+    ARG_TRY(s->ctx, panel_ok(s, j0, w));
+    return factor_range(s, s->A, s->lda, j0, w);
+}
+
+extern "C" int32_t madqp_chol_update_cols(madqp_chol* s, int64_t c0, int64_t cw, int64_t p0, int64_t pw) {
+    if (!s) return MADQP_ERR_ARG;
+    ARG_TRY(s->ctx, panel_ok(s, c0, cw) && panel_ok(s, p0, pw) && p0 + pw <= c0);
+    return panel_update(s->ctx, s->A, s->lda, s->n, c0, p0, cw, p0 + pw);
+}
+
+extern "C" int32_t madqp_chol_panel_doubles(madqp_chol* s, int64_t j0, int64_t w, int64_t* count_host) {
+    if (!s || !count_host) return MADQP_ERR_ARG;
+    ARG_TRY(s->ctx, j0 >= 0 && w > 0 && j0 % NB == 0 && j0 + w <= s->n);
+    const int64_t nblk = (w + NB - 1) / NB;
+    *count_host = PACK_HDR + nblk * WBLK + w * (s->n - j0);
+    return MADQP_OK;
+}
+
+// buf = [info, 0 | inverse diagonal blocks of the panel | L[j0:n, j0+c] for c = 0..w-1]
+extern "C" int32_t madqp_chol_panel_pack(madqp_chol* s, int64_t j0, int64_t w, double* buf) {
+    if (!s) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, panel_ok(s, j0, w) && buf);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    const int64_t nblk = (w + NB - 1) / NB, rows = s->n - j0;
+    hipLaunchKernelGGL(info_store_kernel, dim3(1), dim3(1), 0, ctx->stream, s->d_info, buf);
+    LAUNCH_CHECK(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(buf + PACK_HDR, s->winv + (j0 / NB) * WBLK, nblk * WBLK * sizeof(double),
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync(buf + PACK_HDR + nblk * WBLK, rows * sizeof(double),
+                                  s->A + j0 + j0 * s->lda, s->lda * sizeof(double), rows * sizeof(double),
+                                  (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_chol_panel_unpack(madqp_chol* s, int64_t j0, int64_t w, const double* buf) {
+    if (!s) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, panel_ok(s, j0, w) && buf);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    const int64_t nblk = (w + NB - 1) / NB, rows = s->n - j0;
+    hipLaunchKernelGGL(info_merge_kernel, dim3(1), dim3(1), 0, ctx->stream, s->d_info, buf);
+    LAUNCH_CHECK(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(s->winv + (j0 / NB) * WBLK, buf + PACK_HDR, nblk * WBLK * sizeof(double),
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync(s->A + j0 + j0 * s->lda, s->lda * sizeof(double),
+                                  buf + PACK_HDR + nblk * WBLK, rows * sizeof(double), rows * sizeof(double),
+                                  (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_chol_factor_end(madqp_chol* s, int32_t* info_host) {
+    if (!s) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, s->A && info_host);
     int32_t info = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&info, s->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -500,21 +500,19 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(int64_t n, int64_t npad
 }
 }  // namespace
 
-extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B,
-                                       int64_t ldb, const double* w, const double* base,
-                                       int64_t ldbase, const double* dvec, double* C,
-                                       int64_t ldc) {
-    ARG_TRY(ctx, ctx != nullptr);
+// Lower triangle of C = base + diag(dvec) + B' diag(w) B, restricted to the column ranges
+// [ranges[2r], ranges[2r+1]) (rows >= the range start); ranges == nullptr: all columns.
+static int32_t syrk_assemble_impl(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B, int64_t ldb,
+                                  const double* w, const double* base, int64_t ldbase,
+                                  const double* dvec, double* C, int64_t ldc, int64_t nranges,
+                                  const int64_t* ranges) {
     ARG_TRY(ctx, n >= 0 && kdim >= 0 && C && ldc >= n && (kdim == 0 || (B && ldb >= n)));
     ARG_TRY(ctx, !base || ldbase >= n);
-    GemmArgs g{};
-    g.X = B ? B : C;  // K == 0: never dereferenced
-    g.ldx = ldb;
-    g.Y = g.X;
-    g.ldy = ldb;
-    g.K = kdim;
+    const double* X = B ? B : C;  // K == 0: never dereferenced
+    int64_t ldx = ldb, K = kdim, npad = 0;
     if (w && kdim > 0 && n > 0) {
-        const int64_t npad = (n + BM - 1) / BM * BM, kpad = (kdim + BK - 1) / BK * BK;
+        npad = (n + BM - 1) / BM * BM;
+        const int64_t kpad = (kdim + BK - 1) / BK * BK;
         const size_t bytes = (size_t)kpad * npad * sizeof(double);
         if (bytes > ctx->scaled_bytes) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -535,23 +533,69 @@ extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, 
                                npad, kdim, B, ldb, w, ctx->d_scaled, vec);
             LAUNCH_CHECK(ctx);
         }
-        g.X = g.Y = ctx->d_scaled;
-        g.ldx = g.ldy = npad;
-        g.Mread = g.Nread = npad;
-        g.K = kpad;
+        X = ctx->d_scaled;
+        ldx = npad;
+        K = kpad;
     }
-    g.C = C;
-    g.ldc = ldc;
-    g.Cin = base;
-    g.ldcin = ldbase;
-    g.dvec = dvec;
-    g.alpha = 1.0;
-    g.beta = 1.0;
-    g.M = n;
-    g.N = n;
-    g.diag_off = 0;
-    g.lower_only = 1;
-    return madqp_gemm_tn(ctx, g, MADQP_PROF_SYRK);
+    const int64_t whole[2] = {0, n};
+    if (!ranges) {
+        ranges = whole;
+        nranges = 1;
+    }
+    for (int64_t r = 0; r < nranges; ++r) {
+        const int64_t j0 = ranges[2 * r], j1 = ranges[2 * r + 1];
+        ARG_TRY(ctx, 0 <= j0 && j0 <= j1 && j1 <= n && (j0 % BM == 0));
+        if (j1 == j0) continue;
+        GemmArgs g{};
+        g.X = X + j0;
+        g.ldx = ldx;
+        g.Y = g.X;
+        g.ldy = ldx;
+        g.K = K;
+        if (npad) {
+            g.Mread = npad - j0;
+            g.Nread = std::min<int64_t>(npad - j0, (j1 - j0 + BN - 1) / BN * BN);
+        }
+        g.C = C + j0 + j0 * ldc;
+        g.ldc = ldc;
+        g.Cin = base ? base + j0 + j0 * ldbase : nullptr;
+        g.ldcin = ldbase;
+        g.dvec = dvec ? dvec + j0 : nullptr;
+        g.alpha = 1.0;
+        g.beta = 1.0;
+        g.M = n - j0;
+        g.N = j1 - j0;
+        g.diag_off = 0;
+        g.lower_only = 1;
+        int32_t rc = madqp_gemm_tn(ctx, g, MADQP_PROF_SYRK);
+        if (rc) return rc;
+    }
+    return MADQP_OK;
+}
+
+int32_t madqp_syrk_assemble_ranges(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B, int64_t ldb,
+                                   const double* w, const double* base, int64_t ldbase,
+                                   const double* dvec, double* C, int64_t ldc, int64_t nranges,
+                                   const int64_t* ranges) {
+    return syrk_assemble_impl(ctx, n, kdim, B, ldb, w, base, ldbase, dvec, C, ldc, nranges, ranges);
+}
+
+extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B,
+                                       int64_t ldb, const double* w, const double* base,
+                                       int64_t ldbase, const double* dvec, double* C,
+                                       int64_t ldc) {
+    ARG_TRY(ctx, ctx != nullptr);
+    return syrk_assemble_impl(ctx, n, kdim, B, ldb, w, base, ldbase, dvec, C, ldc, 0, nullptr);
+}
+
+extern "C" int32_t madqp_syrk_assemble_cols(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B,
+                                            int64_t ldb, const double* w, const double* base,
+                                            int64_t ldbase, const double* dvec, double* C, int64_t ldc,
+                                            int64_t nranges, const int64_t* ranges_host) {
+    ARG_TRY(ctx, ctx != nullptr);
+    ARG_TRY(ctx, nranges >= 0 && (nranges == 0 || ranges_host));
+    if (nranges == 0) return MADQP_OK;
+    return syrk_assemble_impl(ctx, n, kdim, B, ldb, w, base, ldbase, dvec, C, ldc, nranges, ranges_host);
 }
 
 // ------------------------------------------------------------------ hardware probe

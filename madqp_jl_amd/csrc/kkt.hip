@@ -340,7 +340,12 @@ static int32_t check_kkt_state(madqp_kkt* k, const madqp_state* st) {
     return MADQP_OK;
 }
 
-extern "C" int32_t madqp_kkt_build(madqp_kkt* k, const madqp_state* st) {
+int32_t madqp_syrk_assemble_ranges(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B, int64_t ldb,
+                                   const double* w, const double* base, int64_t ldbase,
+                                   const double* dvec, double* C, int64_t ldc, int64_t nranges,
+                                   const int64_t* ranges);  // gemm_f64.hip; ranges == nullptr: everything
+
+static int32_t kkt_build_impl(madqp_kkt* k, const madqp_state* st, int64_t nranges, const int64_t* ranges) {
     int32_t r = check_kkt_state(k, st);
     if (r) return r;
     madqp_ctx* ctx = k->ctx;
@@ -352,15 +357,37 @@ extern "C" int32_t madqp_kkt_build(madqp_kkt* k, const madqp_state* st) {
             if (st->n) KLAUNCH(recip_kernel, st->n, st->n, st->pr_diag, k->dn);
             if (k->m) KLAUNCH(slack_diag_kernel, k->m, k->m, k->nx, k->d_slot, k->dn, k->theta);
         }
-        return madqp_syrk_assemble(ctx, k->m, k->nx, k->At, k->ldat, k->dn, nullptr, 0, k->theta, k->K,
-                                   k->ldk);
+        return madqp_syrk_assemble_ranges(ctx, k->m, k->nx, k->At, k->ldat, k->dn, nullptr, 0, k->theta,
+                                          k->K, k->ldk, nranges, ranges);
     }
     if (k->m) {
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(theta_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, k->theta);
     }
-    return madqp_syrk_assemble(ctx, k->nx, k->m, k->A, k->lda, k->theta, k->H, k->ldh, st->pr_diag,
-                               k->K, k->ldk);
+    return madqp_syrk_assemble_ranges(ctx, k->nx, k->m, k->A, k->lda, k->theta, k->H, k->ldh, st->pr_diag,
+                                      k->K, k->ldk, nranges, ranges);
+}
+
+extern "C" int32_t madqp_kkt_build(madqp_kkt* k, const madqp_state* st) {
+    return kkt_build_impl(k, st, 0, nullptr);
+}
+
+// build_kkt! restricted to the block columns [ranges[2r], ranges[2r+1]) of the lower triangle
+// (multi-GPU path: a rank assembles the panels it owns).  Theta and the vectors the solves read
+// are computed in full, so solve!/mul! work on every rank.
+extern "C" int32_t madqp_kkt_build_cols(madqp_kkt* k, const madqp_state* st, int64_t nranges,
+                                        const int64_t* ranges_host) {
+    if (!k) return MADQP_ERR_ARG;
+    ARG_TRY(k->ctx, nranges >= 0 && (nranges == 0 || ranges_host));
+    static const int64_t none[2] = {0, 0};
+    return kkt_build_impl(k, st, nranges ? nranges : 1, nranges ? ranges_host : none);
+}
+
+extern "C" int32_t madqp_kkt_chol(madqp_kkt* k, madqp_chol** chol, int64_t* order) {
+    if (!k || !chol) return MADQP_ERR_ARG;
+    *chol = k->chol;
+    if (order) *order = (k->mode == KKT_NORMAL) ? k->m : k->nx;
+    return MADQP_OK;
 }
 
 extern "C" int32_t madqp_kkt_factorize(madqp_kkt* k, int32_t* info_host) {

@@ -43,6 +43,8 @@ class IPMOptions:
         bound_relax_factor=1e-8, max_ncorr=0, mu_init=1e-1, mu_min=1e-11,
         tol_linear_solve=1e-8, check_residual=False, rethrow_error=False, print_level=0,
         kkt_system="condensed",  # "condensed" (HIPCondensedKKTSystem) or "normal" (HIPNormalKKTSystem, LP)
+        distributed=False,  # True: assembly + Cholesky shared by the ranks of torch.distributed (dist.py)
+        panel_width=None,  # block-column width of the distributed factorisation (multiple of 128)
         driver="python",  # "python": this package drives each kernel; "native": one C call per iteration
     )
 

@@ -97,6 +97,8 @@ class MPCSolver:
         self.dnorm = 0.0
         if self.opt.driver not in ("python", "native"):
             raise ValueError(f"unknown driver {self.opt.driver!r}")
+        if self.opt.distributed and self.opt.driver == "native":
+            raise ValueError("the native driver factorizes on one GPU; use driver='python' with distributed=True")
         self._native = None  # madqp_mpc handle (driver="native")
         self._info = CMpcInfo()
 
@@ -323,11 +325,19 @@ class MPCSolver:
                 self.q = self.obj_scale * qp.q
         if self.kkt is not None:
             self.kkt.close()
+        extra = {}
+        if opt.distributed:  # one KKT system over the ranks of the default process group
+            from . import dist as D
+
+            normal_cls, condensed_cls = D.HIPDistributedNormalKKTSystem, D.HIPDistributedCondensedKKTSystem
+            extra = dict(panel_width=opt.panel_width)
+        else:
+            normal_cls, condensed_cls = HIPNormalKKTSystem, HIPCondensedKKTSystem
         if opt.kkt_system == "normal":
             self.At = self.A.t().contiguous()  # (nx, m): the layout the normal-equations GEMM consumes
-            self.kkt = HIPNormalKKTSystem(be, st, nx, self.ind_ineq, self.H, self.At)
+            self.kkt = normal_cls(be, st, nx, self.ind_ineq, self.H, self.At, **extra)
         else:
-            self.kkt = HIPCondensedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)
+            self.kkt = condensed_cls(be, st, nx, self.ind_ineq, self.H, self.A, **extra)
         self.kkt.initialize()  # :162
         self.init_regularization()  # :163
         self.eval_model()  # :166-169
