@@ -34,11 +34,17 @@ def parse():
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--nx", type=int, default=50000)
-    p.add_argument("--m", type=int, default=20000)
+    p.add_argument("--m", "--ncon", dest="m", type=int, default=20000)
     p.add_argument("--max-ncorr", type=int, default=0)
     p.add_argument("--seed", type=int, default=20250614 + 1)
     p.add_argument("--driver", choices=("native", "python"), default="native",
                    help="host driver of the loop body: csrc/mpc.hip (one C call per iteration) or solver.py")
+    p.add_argument("--kkt", choices=("local", "distributed"), default="local",
+                   help="local: every GPU solves its own QP (weak scaling, the headline); distributed: all "
+                        "GPUs share ONE QP through the panel-cyclic distributed Cholesky (strong scaling)")
+    p.add_argument("--panel-width", type=int, default=None, help="block-column width of --kkt distributed")
+    p.add_argument("--no-distributed-extra", action="store_true",
+                   help="N > 1: skip the additional strong-scaling measurement of the distributed KKT path")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-nx", type=int, default=6000)
     p.add_argument("--profile-all", action="store_true", help="time every kernel class (perturbs the "
@@ -105,8 +111,9 @@ def pmc_traffic(nx, m):
     return None, None
 
 
-def dist_setup(backend="nccl"):
-    """One process per GPU (torch.distributed.run): returns (world, rank, local_rank)."""
+def dist_setup(backend="nccl", share_device=False):
+    """One process per GPU (torch.distributed.run): returns (world, rank, local_rank).
+    ``share_device``: rehearsal with all ranks on device 0 (gloo only)."""
     import torch
     import torch.distributed as dist
 
@@ -115,7 +122,7 @@ def dist_setup(backend="nccl"):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if backend == "nccl" and not share_device:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -155,22 +162,19 @@ def rank_seed(seed, rank):
     return seed + rank
 
 
-def main():
-    args = parse()
+def measure(args, M, be, world, seed, distributed):
+    """Warm-up + the timed region (barrier / sync on both sides, MAX over ranks) for one solver set-up:
+    `distributed` False: this rank's own QP; True: all ranks share ONE QP."""
     import torch
-    import torch.distributed as dist
 
-    world, rank, local_rank = dist_setup("nccl")
-
-    import madqp_jl_amd as M
-
-    be = M.HipBackend(local_rank)
     nx, m = args.nx, args.m
-    dq = M.DeviceQP.synthetic(be, rank_seed(args.seed, rank), nx, m)
+    dq = M.DeviceQP.synthetic(be, seed, nx, m)
     # options of scripts/benchmarks_cpu.jl:35-44 (kkt_system -> condensed, linear_solver -> HIP Cholesky)
     solver = M.MPCSolver(dq, be, max_iter=300, step_rule=M.AdaptiveStep(0.995),
                          regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12,
-                         max_ncorr=args.max_ncorr, scaling=True, driver=args.driver)
+                         max_ncorr=args.max_ncorr, scaling=True, distributed=distributed,
+                         panel_width=args.panel_width if distributed else None,
+                         driver="python" if distributed else args.driver)
     solver.initialize()
     excluded = 0.0  # time of re-initialisations inside the timed region (none unless it converges)
 
@@ -185,9 +189,6 @@ def main():
             excluded += time.perf_counter() - t
         solver.iteration_body()
 
-    def barrier():
-        dist_barrier(world, cuda=True)
-
     for _ in range(args.warmup):
         step()
     mfma_classes = ("syrk", "potrf_gemm", "potrf_trsm", "potrf_diag")
@@ -195,41 +196,84 @@ def main():
     be.prof_reset()
     excluded = 0.0
     f0 = solver.kkt.n_factorizations
-    barrier()
+    dist_barrier(world, cuda=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
+    dist_barrier(world, cuda=True)
     elapsed = time.perf_counter() - t0 - excluded
     prof = be.prof_get()
     be.prof_enable(())
-    nfact = solver.kkt.n_factorizations - f0
+    res = dict(tmax=max_over_ranks(elapsed, world, be.device), prof=prof,
+               nfact=solver.kkt.n_factorizations - f0, k=solver.k,
+               last_trace={k: solver.trace[-1][k] for k in ("k", "inf_pr", "inf_du", "inf_compl", "mu")}
+               if solver.trace else None)
+    if distributed:
+        res["panel_width"] = solver.kkt.panel_width
+        res["panels"] = len(solver.kkt.dchol.panels)
+        res["bytes_broadcast_by_rank0"] = solver.kkt.dchol.bytes_sent
+    solver.close()
+    del solver, dq
+    torch.cuda.empty_cache()
+    return res
 
-    tmax = max_over_ranks(elapsed, world, be.device)
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world, rank, local_rank = dist_setup(os.environ.get("MADQP_DIST_BACKEND", "nccl"),
+                                         share_device=bool(os.environ.get("MADQP_DIST_SHARE_DEVICE")))
+    if os.environ.get("MADQP_DIST_SHARE_DEVICE"):
+        local_rank = 0  # rehearsal: several ranks on one GPU (gloo)
+
+    import madqp_jl_amd as M
+
+    be = M.HipBackend(local_rank)
+    nx, m = args.nx, args.m
+    shared = args.kkt == "distributed"
+    res = measure(args, M, be, world, args.seed if shared else rank_seed(args.seed, rank), shared)
+    extra = None
+    if world > 1 and not shared and not args.no_distributed_extra:
+        # the same workload as ONE QP over all ranks (strong scaling of the distributed KKT path);
+        # reported beside the headline number, never instead of it
+        try:
+            extra = measure(args, M, be, world, args.seed, True)
+        except Exception as e:  # keep the headline line even if the extra leg fails
+            extra = {"error": f"{type(e).__name__}: {e}"[:300]}
+    tmax, prof, nfact = res["tmax"], res["prof"], res["nfact"]
 
     if rank == 0:
         # dominant kernel: gemm_tn_f64_kernel (assembly + panel updates + panel x inverse block)
         gemm_ms = prof["syrk"][0] + prof["potrf_gemm"][0] + prof["potrf_trsm"][0]
         gemm_launches = prof["syrk"][1] + prof["potrf_gemm"][1] + prof["potrf_trsm"][1]
         alg_flops = nfact * (m * nx * nx + nx ** 3 / 3.0)  # SYRK m nx^2 + POTRF nx^3/3
+        if shared:
+            alg_flops /= world  # rank 0's share of the MFMA work (cyclic deal of the block columns)
         achieved = alg_flops / (gemm_ms * 1e-3) * 1e-12 if gemm_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(nx, m)
+        if shared and world > 1:
+            traffic, traffic_src = None, None
+        what = ("ONE QP shared by all GPUs (panel-cyclic distributed assembly + Cholesky, madqp_jl_amd/dist.py)"
+                if shared else "one independent QP per GPU")
         out = {
             "metric": "IPM iterations/sec (Mehrotra predictor-corrector, condensed KKT + Cholesky), dense QP fp64",
-            "value": job_value(world, args.steps, tmax),
+            "value": (args.steps / tmax) if shared else job_value(world, args.steps, tmax),
             "unit": "iterations/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shared else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"synthetic dense QP nx={nx} m={m} (0<=x<=1, 0<=Ax<=1, Wigner H, Gaussian A), "
-                                   f"one independent QP per GPU, max_ncorr={args.max_ncorr}",
-                       "nx": nx, "m": m, "n_slack": m, "max_ncorr": args.max_ncorr, "driver": args.driver,
+                                   f"{what}, max_ncorr={args.max_ncorr}",
+                       "nx": nx, "m": m, "n_slack": m, "max_ncorr": args.max_ncorr,
+                       "driver": "python" if shared else args.driver, "kkt": args.kkt,
                        "options": "scripts/benchmarks_cpu.jl:35-44 with kkt_system=HIPCondensedKKTSystem, "
                                   "linear_solver=HIPCholeskySolver"},
             "kkt_factor_solve_ms": {
@@ -246,15 +290,28 @@ def main():
                 "algorithmic_flops_per_launch": alg_flops / max(gemm_launches, 1),
                 "split": {k: {"ms": prof[k][0], "launches": prof[k][1]} for k in prof if prof[k][1]},
             },
-            "iterations_done": solver.k,
-            "last_trace": {k: solver.trace[-1][k] for k in ("k", "inf_pr", "inf_du", "inf_compl", "mu")}
-            if solver.trace else None,
+            "iterations_done": res["k"],
+            "last_trace": res["last_trace"],
         }
+        if shared:
+            out["distributed"] = {k: res[k] for k in ("panel_width", "panels", "bytes_broadcast_by_rank0")}
+        if extra is not None:
+            if "error" in extra:
+                out["distributed_kkt"] = extra
+            else:
+                ep = extra["prof"]
+                out["distributed_kkt"] = {
+                    "what": "the same workload as ONE QP over all GPUs (strong scaling; madqp_jl_amd/dist.py)",
+                    "value": args.steps / extra["tmax"], "unit": "iterations/s",
+                    "ms_per_step": extra["tmax"] / args.steps * 1e3, "scaling": "strong",
+                    "panel_width": extra["panel_width"], "panels": extra["panels"],
+                    "bytes_broadcast_by_rank0": extra["bytes_broadcast_by_rank0"],
+                    "rank0_ms": {k: ep[k][0] / max(extra["nfact"], 1) for k in ep if ep[k][1]},
+                }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, nx, m)
         print(json.dumps(out), flush=True)
 
-    solver.close()
     be.close()
     if world > 1:
         dist.destroy_process_group()

@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -26,9 +28,6 @@ def test_two_ranks_gloo(tmp_path):
     assert abs(recs[0]["value"] - 2 * 3 / recs[0]["tmax"]) < 1e-9
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "only rank 0 prints the JSON line"
-
-
-import pytest
 
 
 @pytest.mark.parametrize("world,n,nb,port", [(2, 700, 128, 29519), (3, 1000, 256, 29521)])
