@@ -262,6 +262,8 @@ int32_t madqp_chol_factor_begin(madqp_chol* s, double* A, int64_t lda);
 int32_t madqp_chol_factor_panel(madqp_chol* s, int64_t j0, int64_t w);
 /* A[c0:n, c0:c0+cw] -= L[c0:n, p0:p0+pw] L[c0:c0+cw, p0:p0+pw]'  (lower part; p0+pw <= c0) */
 int32_t madqp_chol_update_cols(madqp_chol* s, int64_t c0, int64_t cw, int64_t p0, int64_t pw);
+/* the same update for ncols panels of the caller, cols_host = (start, width) pairs ascending, one launch */
+int32_t madqp_chol_update_multi(madqp_chol* s, int64_t ncols, const int64_t* cols_host, int64_t p0, int64_t pw);
 /* packed image of a factored panel: [info, 0 | inverse diagonal blocks | L[j0:n, j0:j0+w]] */
 int32_t madqp_chol_panel_doubles(madqp_chol* s, int64_t j0, int64_t w, int64_t* count_host);
 int32_t madqp_chol_panel_pack(madqp_chol* s, int64_t j0, int64_t w, double* buf);

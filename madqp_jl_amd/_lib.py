@@ -122,6 +122,7 @@ _SIGNATURES = {
     "madqp_chol_factor_begin": [vp, vp, i64],
     "madqp_chol_factor_panel": [vp, i64, i64],
     "madqp_chol_update_cols": [vp, i64, i64, i64, i64],
+    "madqp_chol_update_multi": [vp, i64, pi64, i64, i64],
     "madqp_chol_panel_doubles": [vp, i64, i64, pi64],
     "madqp_chol_panel_pack": [vp, i64, i64, vp],
     "madqp_chol_panel_unpack": [vp, i64, i64, vp],

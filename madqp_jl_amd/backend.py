@@ -329,6 +329,13 @@ class HipBackend:
     def chol_update_cols(self, ch, c0, cw, p0, pw):
         self._ck(self.lib.madqp_chol_update_cols(ch, c0, cw, p0, pw))
 
+    def chol_update_multi(self, ch, cols, p0, pw):
+        """``cols``: [(start, width)] ascending, all right of the source panel; one launch."""
+        flat = [int(v) for c in cols for v in c]
+        if flat:
+            arr = (C.c_int64 * len(flat))(*flat)
+            self._ck(self.lib.madqp_chol_update_multi(ch, len(flat) // 2, arr, p0, pw))
+
     def chol_panel_doubles(self, ch, j0, w) -> int:
         n = C.c_int64()
         self._ck(self.lib.madqp_chol_panel_doubles(ch, j0, w, C.byref(n)))

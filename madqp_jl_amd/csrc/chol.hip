@@ -16,6 +16,8 @@
 // (4 n^2 bytes each).
 #include <algorithm>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -531,6 +533,43 @@ extern "C" int32_t madqp_chol_update_cols(madqp_chol* s, int64_t c0, int64_t cw,
     if (!s) return MADQP_ERR_ARG;
     ARG_TRY(s->ctx, panel_ok(s, c0, cw) && panel_ok(s, p0, pw) && p0 + pw <= c0);
     return panel_update(s->ctx, s->A, s->lda, s->n, c0, p0, cw, p0 + pw);
+}
+
+// The same update for several panels of the caller in ONE launch: cols_host = ncols pairs
+// (start, width), ascending; all of them right of the source panel [p0, p0+pw).
+extern "C" int32_t madqp_chol_update_multi(madqp_chol* s, int64_t ncols, const int64_t* cols_host, int64_t p0,
+                                           int64_t pw) {
+    if (!s) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, ncols >= 0 && (ncols == 0 || cols_host) && panel_ok(s, p0, pw));
+    if (ncols == 0) return MADQP_OK;
+    const int64_t n = s->n, lda = s->lda, cmin = cols_host[0];
+    std::vector<int64_t> rel((size_t)(2 * ncols));
+    for (int64_t r = 0; r < ncols; ++r) {
+        const int64_t c0 = cols_host[2 * r], cw = cols_host[2 * r + 1];
+        ARG_TRY(ctx, panel_ok(s, c0, cw) && p0 + pw <= c0 && (r == 0 || c0 >= cols_host[2 * r - 2] + cols_host[2 * r - 1]));
+        rel[(size_t)(2 * r)] = c0 - cmin;
+        rel[(size_t)(2 * r + 1)] = c0 + cw - cmin;
+    }
+    GemmArgs g{};
+    g.X = s->A + cmin + p0 * lda;
+    g.ldx = lda;
+    g.Y = g.X;
+    g.ldy = lda;
+    g.C = s->A + cmin + cmin * lda;
+    g.ldc = lda;
+    g.Cin = g.C;
+    g.ldcin = lda;
+    g.alpha = -1.0;
+    g.beta = 1.0;
+    g.M = n - cmin;
+    g.N = n - cmin;
+    g.K = pw;
+    const int64_t npad = (n + NB - 1) / NB * NB;
+    if (lda >= npad) g.Mread = g.Nread = npad - cmin;
+    g.diag_off = 0;
+    g.lower_only = 1;
+    return madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_GEMM, rel.data(), ncols);
 }
 
 extern "C" int32_t madqp_chol_panel_doubles(madqp_chol* s, int64_t j0, int64_t w, int64_t* count_host) {

@@ -103,7 +103,11 @@ struct GemmArgs {
     int64_t diag_off;  // global_row(i) - global_col(j) = i - j + diag_off
     int lower_only;    // 1: write only elements with i + diag_off >= j; skip tiles above
 };
-int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls);
+// cols: optional host list of ncols column ranges [cols[2r], cols[2r+1]) (multiples of 128 relative to
+// C) -- only output tiles whose columns fall in one of them are computed (multi-GPU path: the block
+// columns a rank owns, in ONE launch)
+int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int64_t* cols = nullptr,
+                      int64_t ncols = 0);
 
 void madqp_gemm_release_tables(madqp_ctx* ctx);
 

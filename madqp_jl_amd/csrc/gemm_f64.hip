@@ -337,11 +337,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
 
 struct TableKey {
     int64_t tm, tn, lower, doff;
+    uint64_t cols_hash;  // 0: all tile columns
     bool operator<(const TableKey& o) const {
         if (tm != o.tm) return tm < o.tm;
         if (tn != o.tn) return tn < o.tn;
         if (lower != o.lower) return lower < o.lower;
-        return doff < o.doff;
+        if (doff != o.doff) return doff < o.doff;
+        return cols_hash < o.cols_hash;
     }
 };
 struct TableVal {
@@ -378,15 +380,28 @@ void madqp_gemm_release_tables(madqp_ctx* ctx) {
     for (auto& kv : mine) (void)hipFree(kv.second.d);
 }
 
-int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls) {
+int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int64_t* cols, int64_t ncols) {
     ARG_TRY(ctx, a.M >= 0 && a.N >= 0 && a.K >= 0 && a.X && a.Y && a.C);
     if (a.M == 0 || a.N == 0) return MADQP_OK;
     const int64_t tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     ARG_TRY(ctx, tiles_m < 65536 && tiles_n < 32768);
+    uint64_t cols_hash = 0;
+    std::vector<char> col_on;
+    if (cols) {
+        col_on.assign((size_t)tiles_n, 0);
+        cols_hash = 1469598103934665603ull;  // FNV-1a over the range list
+        for (int64_t r = 0; r < 2 * ncols; ++r) {
+            ARG_TRY(ctx, cols[r] >= 0 && cols[r] <= a.N && (cols[r] % BN == 0 || cols[r] == a.N));
+            cols_hash = (cols_hash ^ (uint64_t)cols[r]) * 1099511628211ull;
+        }
+        if (cols_hash == 0) cols_hash = 1;
+        for (int64_t r = 0; r < ncols; ++r)
+            for (int64_t t = cols[2 * r] / BN; t < (cols[2 * r + 1] + BN - 1) / BN; ++t) col_on[(size_t)t] = 1;
+    }
     // diag_off in tile units must be exact for the tile-skip test used when building the table
     TableKey key{tiles_m, tiles_n,
                  (a.lower_only ? 1 : 0) | ((a.M % BM) != 0 ? 2 : 0) | ((a.N % BN) != 0 ? 4 : 0),
-                 a.lower_only ? a.diag_off : 0};
+                 a.lower_only ? a.diag_off : 0, cols_hash};
     auto& cache = tables_of(ctx);
     auto it = cache.find(key);
     if (it == cache.end()) {
@@ -400,6 +415,7 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls) {
         // the tail of the launch.
         const bool m_edge = (a.M % BM) != 0, n_edge = (a.N % BN) != 0;
         auto active = [&](int64_t tm, int64_t tn) {
+            if (cols && !col_on[(size_t)tn]) return false;
             return !(a.lower_only && (tm * BM + BM - 1 + a.diag_off < tn * BN));
         };
         auto is_edge = [&](int64_t tm, int64_t tn) {
@@ -537,40 +553,34 @@ static int32_t syrk_assemble_impl(madqp_ctx* ctx, int64_t n, int64_t kdim, const
         ldx = npad;
         K = kpad;
     }
-    const int64_t whole[2] = {0, n};
-    if (!ranges) {
-        ranges = whole;
-        nranges = 1;
-    }
-    for (int64_t r = 0; r < nranges; ++r) {
-        const int64_t j0 = ranges[2 * r], j1 = ranges[2 * r + 1];
-        ARG_TRY(ctx, 0 <= j0 && j0 <= j1 && j1 <= n && (j0 % BM == 0));
-        if (j1 == j0) continue;
-        GemmArgs g{};
-        g.X = X + j0;
-        g.ldx = ldx;
-        g.Y = g.X;
-        g.ldy = ldx;
-        g.K = K;
-        if (npad) {
-            g.Mread = npad - j0;
-            g.Nread = std::min<int64_t>(npad - j0, (j1 - j0 + BN - 1) / BN * BN);
+    if (ranges) {
+        bool any = false;
+        for (int64_t r = 0; r < nranges; ++r) {
+            ARG_TRY(ctx, 0 <= ranges[2 * r] && ranges[2 * r] <= ranges[2 * r + 1] && ranges[2 * r + 1] <= n &&
+                             ranges[2 * r] % BM == 0);
+            any = any || ranges[2 * r + 1] > ranges[2 * r];
         }
-        g.C = C + j0 + j0 * ldc;
-        g.ldc = ldc;
-        g.Cin = base ? base + j0 + j0 * ldbase : nullptr;
-        g.ldcin = ldbase;
-        g.dvec = dvec ? dvec + j0 : nullptr;
-        g.alpha = 1.0;
-        g.beta = 1.0;
-        g.M = n - j0;
-        g.N = j1 - j0;
-        g.diag_off = 0;
-        g.lower_only = 1;
-        int32_t rc = madqp_gemm_tn(ctx, g, MADQP_PROF_SYRK);
-        if (rc) return rc;
+        if (!any) return MADQP_OK;
     }
-    return MADQP_OK;
+    GemmArgs g{};
+    g.X = X;
+    g.ldx = ldx;
+    g.Y = X;
+    g.ldy = ldx;
+    g.K = K;
+    if (npad) g.Mread = g.Nread = npad;
+    g.C = C;
+    g.ldc = ldc;
+    g.Cin = base;
+    g.ldcin = ldbase;
+    g.dvec = dvec;
+    g.alpha = 1.0;
+    g.beta = 1.0;
+    g.M = n;
+    g.N = n;
+    g.diag_off = 0;
+    g.lower_only = 1;
+    return madqp_gemm_tn(ctx, g, MADQP_PROF_SYRK, ranges, ranges ? nranges : 0);  // one launch, masked columns
 }
 
 int32_t madqp_syrk_assemble_ranges(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B, int64_t ldb,

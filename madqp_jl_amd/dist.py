@@ -55,7 +55,7 @@ class DistributedCholesky:
     """Panel-cyclic right-looking Cholesky driver above ``madqp_chol_*`` (see the module docstring).
 
     ``ops`` provides the rank-local primitives (``HipBackend`` on the GPU, a numpy double in the CPU
-    tests): chol_factor_begin / chol_factor_panel / chol_update_cols / chol_panel_doubles /
+    tests): chol_factor_begin / chol_factor_panel / chol_update_cols / chol_update_multi / chol_panel_doubles /
     chol_panel_pack / chol_panel_unpack / chol_factor_end.  ``group``: the process group (None = world).
     """
 
@@ -115,9 +115,8 @@ class DistributedCholesky:
                     ops.chol_factor_panel(ch, *self.panels[nxt])
                     ops.chol_panel_pack(ch, *self.panels[nxt], self.bufs[nxt % 2])
                 work = self._bcast(nxt)
-            for q in mine:  # remaining rank-local updates by panel p (run under the transfer of p+1)
-                if q > nxt:
-                    ops.chol_update_cols(ch, *self.panels[q], j, w)
+            # remaining rank-local updates by panel p, one launch (they run under the transfer of p+1)
+            ops.chol_update_multi(ch, [self.panels[q] for q in mine if q > nxt], j, w)
         return ops.chol_factor_end(ch)
 
 

@@ -49,6 +49,10 @@ class NumpyPanelOps:
         low = np.tril(np.ones((self.n - c0, cw), dtype=bool))
         blk[low] -= upd[low]
 
+    def chol_update_multi(self, ch, cols, p0, pw):
+        for c0, cw in cols:
+            self.chol_update_cols(ch, c0, cw, p0, pw)
+
     def chol_panel_doubles(self, ch, j, w):
         return 2 + w * (self.n - j)
 
