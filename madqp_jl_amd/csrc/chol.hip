@@ -15,10 +15,13 @@
 // solves of the two triangular sweeps into 128 x 128 mat-vecs; the sweeps are HBM bound
 // (4 n^2 bytes each).
 #include <algorithm>
+#include <cstdlib>
 
 #include <vector>
 
 #include "common.h"
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int NB = 128;    // diagonal block
@@ -218,106 +221,245 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
     }
 }
 
-// ---- triangular sweeps: one launch per 128-column block ------------------------------------
-// Both sweeps are "right-looking": as soon as the solution of block j is known it is applied to
-// the part of the vector not yet solved, so every workgroup of the launch finishes its outputs
-// alone (no cross-workgroup reduction).  Each workgroup recomputes the small diagonal product
-//   x_j = W_jj v_j (forward, W column-major image)   /   x_j = W_jj' v_j (backward, row-major image)
-// itself (128 x 128, the inverse block is shared through L2) instead of waiting for a separate
-// launch; workgroup 0 stores x_j, workgroups g >= 1 update one 128-entry slice of the vector:
-//   forward :  b[R] -= L[R, J] x_j      R = 128 rows below the block
-//   backward:  y[C] -= L[J, C]' x_j     C = 128 columns left of the block
-// The vector being updated and the vector receiving the solution are different arrays, so no
-// workgroup reads what another one writes.  4 n^2 bytes of L per sweep: HBM bound.
-__device__ __forceinline__ void block_matvec(const double* __restrict__ img, const double* __restrict__ v,
-                                             int w, double* vs, double (*part)[NB], double* xs) {
-    const int i = threadIdx.x & (NB - 1), p = threadIdx.x >> 7;
-    if (threadIdx.x < NB) vs[i] = (i < w) ? v[i] : 0.0;
-    __syncthreads();
-    double acc = 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int j = p * 16 + q;
-        acc += img[i + j * NB] * vs[j];
-    }
-    part[p][i] = acc;
-    __syncthreads();
-    if (threadIdx.x < NB) {
-        double sum = part[0][i];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) sum += part[q][i];
-        xs[i] = sum;
-    }
-    __syncthreads();
+// ---- triangular sweeps, one launch each ---------------------------------------------------------
+// A sweep over the 128-row blocks is a chain: block r needs the solutions of all blocks before it.
+// Instead of one launch per block (391 launches per sweep at n = 50 000, each with its own ramp and
+// tail) ONE launch runs a workgroup per block; workgroup r streams its own tiles L[r, j] (forward) /
+// L[j, r] (backward) as the x_j appear and then solves its diagonal block with the stored inverse.
+//   * order: a workgroup draws its block index from a ticket counter, so it only ever waits for
+//     blocks drawn earlier, which are resident or finished -- the grid always drains, whatever the
+//     dispatch order and however many workgroups fit on the chip;
+//   * hand-off: x_j is published as 128 naturally aligned 8-byte write-through (sc1) stores into a
+//     vector pre-filled with a NaN sentinel; consumers poll the values themselves with sc1 loads
+//     (data = tag: no flag, no fence; MI355X_MICROARCH.md "handoff-1to1", ~1 us per hop);
+//   * streaming: 16 waves x (2 rows per lane) x (4 columns per wave) = half a tile per stage, two
+//     stages in flight in registers while the wave waits for the next x_j; the inverse diagonal
+//     block sits in registers from the start, so the critical path per block is
+//     poll -> 8 fma -> cross-wave sum -> 128 x 128 product -> publish.
+// Summation order is fixed by the thread mapping: results do not depend on timing.
+constexpr unsigned long long SWEEP_SENTINEL = 0x7FF8A5A57FF8A5A5ull;  // a NaN no arithmetic produces
+constexpr int SWEEP_SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ unsigned long long ld_sc1_u64(const double* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1_f64(double* p, double v) {
+    unsigned long long u = __double_as_longlong(v);
+    if (v != v) u = 0x7FF8000000000000ull;  // never publish the sentinel pattern
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(1024) void trsv_fwd_step_kernel(const double* __restrict__ L, int64_t lda,
-                                                             const double* __restrict__ Wcm,
-                                                             double* __restrict__ b,
-                                                             double* __restrict__ yout, int64_t jb,
-                                                             int w, int64_t n) {
-    __shared__ double vs[NB], xs[NB];
-    __shared__ double part[8][NB];
-    block_matvec(Wcm, b + jb, w, vs, part, xs);
-    const int i = threadIdx.x & (NB - 1), p = threadIdx.x >> 7;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < w) yout[jb + threadIdx.x] = xs[threadIdx.x];
-        return;
-    }
-    const int64_t row = jb + w + (int64_t)(blockIdx.x - 1) * NB + i;
-    double acc = 0.0;
-    if (row < n) {
-        const double* Lp = L + row + jb * lda;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int c = p * 16 + q;
-            if (c < w) acc += Lp[(int64_t)c * lda] * xs[c];
+// wave 0: wait until the 128 entries of block j of `x` have been published, copy them to LDS
+// (entries at or beyond n are zero).  Returns with the error flag set if the producer never shows up.
+__device__ __forceinline__ void sweep_poll_block(const double* __restrict__ x, int64_t j, int64_t n,
+                                                 double* __restrict__ dst, int32_t* __restrict__ err,
+                                                 int lane) {
+    const int64_t i0 = j * NB + 2 * lane;
+    unsigned long long u0 = 0, u1 = 0;
+    int spins = 0;
+    bool wait0 = i0 < n, wait1 = i0 + 1 < n;
+    while (wait0 || wait1) {
+        if (wait0) {
+            u0 = ld_sc1_u64(x + i0);
+            wait0 = (u0 == SWEEP_SENTINEL);
+        }
+        if (wait1) {
+            u1 = ld_sc1_u64(x + i0 + 1);
+            wait1 = (u1 == SWEEP_SENTINEL);
+        }
+        if ((wait0 || wait1) && ++spins > SWEEP_SPIN_LIMIT) {
+            atomicExch(err, 1);
+            u0 = u1 = 0x7FF8000000000000ull;
+            break;
         }
     }
-    part[p][i] = acc;
-    __syncthreads();
-    if (threadIdx.x < NB && row < n) {
-        double sum = part[0][i];
+    dst[2 * lane] = (i0 < n) ? __longlong_as_double(u0) : 0.0;
+    dst[2 * lane + 1] = (i0 + 1 < n) ? __longlong_as_double(u1) : 0.0;
+}
+
+// half a 128 x 128 column-major tile: rows 2*lane, 2*lane+1 and the 4 columns of this wave
+__device__ __forceinline__ void sweep_load_half(const double* __restrict__ base, int64_t ld, bool ok0,
+                                                bool ok1, bool vec, double2_t (&dst)[4]) {
 #pragma unroll
-        for (int q = 1; q < 8; ++q) sum += part[q][i];
-        b[row] -= sum;
+    for (int q = 0; q < 4; ++q) {
+        const double* p = base + (int64_t)q * ld;
+        if (vec && ok1) {
+            dst[q] = *reinterpret_cast<const double2_t*>(p);
+        } else {
+            dst[q].x = ok0 ? p[0] : 0.0;
+            dst[q].y = ok1 ? p[1] : 0.0;
+        }
     }
 }
 
-__global__ __launch_bounds__(1024) void trsv_bwd_step_kernel(const double* __restrict__ L, int64_t lda,
-                                                             const double* __restrict__ Wrm,
-                                                             double* __restrict__ y,
-                                                             double* __restrict__ xout, int64_t jb,
-                                                             int w) {
-    __shared__ double vs[NB], xs[NB];
-    __shared__ double part[8][NB];
-    block_matvec(Wrm, y + jb, w, vs, part, xs);
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < w) xout[jb + threadIdx.x] = xs[threadIdx.x];
-        return;
+// x_r = W (v) with the inverse block image held in registers (wh[0], wh[1] = the two halves), v in LDS;
+// the block's 128 results are published to out[row0 + i], i < w.
+__device__ __forceinline__ void sweep_diag_publish(const double2_t (&w0)[4], const double2_t (&w1)[4],
+                                                   const double* __restrict__ vs, double (*red)[NB],
+                                                   double* __restrict__ out, int64_t row0, int w, int tid,
+                                                   int lane, int wave) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double v0 = vs[wave * 4 + q], v1 = vs[64 + wave * 4 + q];
+        a0 = __builtin_fma(w0[q].x, v0, a0);
+        a1 = __builtin_fma(w0[q].y, v0, a1);
+        a0 = __builtin_fma(w1[q].x, v1, a0);
+        a1 = __builtin_fma(w1[q].y, v1, a1);
     }
-    // 16 waves: wave v sums rows [64h, 64h+64) of the block for columns [16g, 16g+16), h = v&1, g = v>>1
-    const int lane = threadIdx.x & 63, v = threadIdx.x >> 6;
-    const int h = v & 1, g = v >> 1;
-    const int r = 64 * h + lane;
-    const int64_t c0 = (int64_t)(blockIdx.x - 1) * NB + 16 * g;  // columns left of the block (< jb)
-    const double xr = (r < w) ? xs[r] : 0.0;
-    const double* Lp = L + (jb + r) + c0 * lda;
-    double sums[16];
+    red[wave][2 * lane] = a0;
+    red[wave][2 * lane + 1] = a1;
+    __syncthreads();
+    if (tid < w) {
+        double sum = red[0][tid];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) sums[q] = (r < w) ? Lp[(int64_t)q * lda] * xr : 0.0;
+        for (int q = 1; q < 16; ++q) sum += red[q][tid];
+        st_sc1_f64(out + row0 + tid, sum);
+    }
+}
+
+__global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __restrict__ L, int64_t lda,
+                                                              const double* __restrict__ winv,
+                                                              const double* __restrict__ b,
+                                                              double* __restrict__ y, int64_t n,
+                                                              int32_t* __restrict__ ctl, int vec) {
+    __shared__ double xs[2][NB];
+    __shared__ double red[16][NB];
+    __shared__ double vs[NB];
+    __shared__ int s_r;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_r = atomicAdd(&ctl[1], 1);
+    __syncthreads();
+    const int r = s_r;
+    const int64_t row0 = (int64_t)r * NB;
+    const int w = (int)((n - row0 < NB) ? (n - row0) : NB);
+    const bool ok0 = row0 + 2 * lane < n, ok1 = row0 + 2 * lane + 1 < n;
+    // inverse diagonal block (column-major image, zero padded, 16-byte aligned): registers
+    double2_t W0[4], W1[4];
+    {
+        const double* Wcm = winv + (int64_t)r * WBLK + 2 * lane;
+        sweep_load_half(Wcm + (int64_t)(wave * 4) * NB, NB, true, true, true, W0);
+        sweep_load_half(Wcm + (int64_t)(64 + wave * 4) * NB, NB, true, true, true, W1);
+    }
+    double a0 = 0.0, a1 = 0.0;
+    const double* Lr = L + row0 + 2 * lane + (int64_t)(wave * 4) * lda;  // this thread's corner of tile (r, 0)
+    double2_t A[4], B[4];
+    if (r > 0) sweep_load_half(Lr, lda, ok0, ok1, vec, A);
+    for (int j = 0; j < r; ++j) {
+        const double* Tj = Lr + (int64_t)j * NB * lda;
+        sweep_load_half(Tj + 64 * lda, lda, ok0, ok1, vec, B);
+        if (wave == 0) sweep_poll_block(y, j, n, xs[j & 1], &ctl[3], lane);
+        __syncthreads();
+        const double* xj = xs[j & 1];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        double t = sums[q];
+        for (int q = 0; q < 4; ++q) {
+            const double xv = xj[wave * 4 + q];
+            a0 = __builtin_fma(A[q].x, xv, a0);
+            a1 = __builtin_fma(A[q].y, xv, a1);
+        }
+        if (j + 1 < r) sweep_load_half(Tj + (int64_t)NB * lda, lda, ok0, ok1, vec, A);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-        if (lane == 0) part[h][16 * g + q] = t;
+        for (int q = 0; q < 4; ++q) {
+            const double xv = xj[64 + wave * 4 + q];
+            a0 = __builtin_fma(B[q].x, xv, a0);
+            a1 = __builtin_fma(B[q].y, xv, a1);
+        }
+    }
+    red[wave][2 * lane] = a0;
+    red[wave][2 * lane + 1] = a1;
+    __syncthreads();
+    if (tid < NB) {
+        double v = 0.0;
+        if (tid < w) {
+            double sum = red[0][tid];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) sum += red[q][tid];
+            v = b[row0 + tid] - sum;
+        }
+        vs[tid] = v;
     }
     __syncthreads();
-    if (threadIdx.x < NB) {
-        const int64_t c = (int64_t)(blockIdx.x - 1) * NB + threadIdx.x;
-        y[c] -= part[0][threadIdx.x] + part[1][threadIdx.x];
+    sweep_diag_publish(W0, W1, vs, red, y, row0, w, tid, lane, wave);
+}
+
+__global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __restrict__ L, int64_t lda,
+                                                              const double* __restrict__ winv,
+                                                              const double* __restrict__ y,
+                                                              double* __restrict__ x, int64_t n,
+                                                              int32_t* __restrict__ ctl, int vec) {
+    __shared__ double xs[2][NB];
+    __shared__ double red[16][NB];
+    __shared__ double vs[NB];
+    __shared__ int s_r;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = (int)((n + NB - 1) / NB);
+    if (tid == 0) s_r = nblk - 1 - atomicAdd(&ctl[2], 1);
+    __syncthreads();
+    const int r = s_r;
+    const int64_t col0 = (int64_t)r * NB;
+    const int w = (int)((n - col0 < NB) ? (n - col0) : NB);
+    // W' v through the row-major image: Wrm[c + r*NB] = W(r, c) -> output index c is the fast one
+    double2_t W0[4], W1[4];
+    {
+        const double* Wrm = winv + (int64_t)r * WBLK + NB * NB + 2 * lane;
+        sweep_load_half(Wrm + (int64_t)(wave * 4) * NB, NB, true, true, true, W0);
+        sweep_load_half(Wrm + (int64_t)(64 + wave * 4) * NB, NB, true, true, true, W1);
     }
+    // this thread's columns: col0 + h*64 + wave*4 + q; rows 2*lane, 2*lane+1 of the row block j
+    double acc[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[h][q] = 0.0;
+    const bool colok = true;  // blocks left of the last one are whole; block r's own columns < n hold below
+    (void)colok;
+    const double* Lc = L + 2 * lane + (col0 + wave * 4) * lda;  // + row block offset
+    double2_t A[4], B[4];
+    const int jlast = nblk - 1;
+    auto rows_ok = [&](int j, bool& o0, bool& o1) {
+        const int64_t i0 = (int64_t)j * NB + 2 * lane;
+        o0 = i0 < n;
+        o1 = i0 + 1 < n;
+    };
+    // columns of block r beyond n do not exist only when r is the last block: then there are no tiles
+    if (r < jlast) {
+        bool o0, o1;
+        rows_ok(jlast, o0, o1);
+        sweep_load_half(Lc + (int64_t)jlast * NB, lda, o0, o1, vec, A);
+    }
+    for (int j = jlast; j > r; --j) {
+        bool o0, o1;
+        rows_ok(j, o0, o1);
+        const double* Tj = Lc + (int64_t)j * NB;
+        sweep_load_half(Tj + 64 * lda, lda, o0, o1, vec, B);
+        if (wave == 0) sweep_poll_block(x, j, n, xs[j & 1], &ctl[3], lane);
+        __syncthreads();
+        const double x0 = xs[j & 1][2 * lane], x1 = xs[j & 1][2 * lane + 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[0][q] = __builtin_fma(A[q].y, x1, __builtin_fma(A[q].x, x0, acc[0][q]));
+        if (j - 1 > r) {
+            bool p0, p1;
+            rows_ok(j - 1, p0, p1);
+            sweep_load_half(Tj - NB, lda, p0, p1, vec, A);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[1][q] = __builtin_fma(B[q].y, x1, __builtin_fma(B[q].x, x0, acc[1][q]));
+    }
+    // column sums over the 64 lanes (fixed butterfly), then v = y_r - sums
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double t = acc[h][q];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0) vs[h * 64 + wave * 4 + q] = t;
+        }
+    __syncthreads();
+    if (tid < NB) vs[tid] = (tid < w) ? (y[col0 + tid] - vs[tid]) : 0.0;
+    __syncthreads();
+    sweep_diag_publish(W0, W1, vs, red, x, col0, w, tid, lane, wave);
 }
 }  // namespace
 
@@ -337,7 +479,7 @@ extern "C" int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out
     const int64_t nblk = std::max<int64_t>(1, (n + NB - 1) / NB);
     hipError_t e = hipMalloc(&s->winv, nblk * WBLK * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&s->tmp, std::max<int64_t>(NB, n) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&s->d_info, sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&s->d_info, 8 * sizeof(int32_t));  // [0] info, [1..3] sweep tickets / error
     if (e != hipSuccess) {
         madqp_chol_destroy(s);
         return madqp_fail(ctx, MADQP_ERR_ALLOC, "madqp_chol_create(%lld): %s", (long long)n,
@@ -632,23 +774,20 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
     if (!s->A) return madqp_fail(ctx, MADQP_ERR_STATE, "madqp_chol_solve before madqp_chol_factor");
     const int64_t n = s->n, lda = s->lda;
     const double* A = s->A;
-    // forward: L y = b   (b updated in place below the block, y collected in s->tmp)
+    if (n == 0) return MADQP_OK;
     ProfScope ps(ctx, MADQP_PROF_TRSV);
-    for (int64_t jb = 0; jb < n; jb += NB) {
-        const int64_t w = std::min<int64_t>(NB, n - jb);
-        const double* Wcm = s->winv + (jb / NB) * WBLK;
-        const int64_t below = n - jb - w;
-        hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3((unsigned)(1 + (below + NB - 1) / NB)), dim3(1024), 0,
-                           ctx->stream, A, lda, Wcm, rhs, s->tmp, jb, (int)w, n);
+    {
+        // one launch per sweep (see trsv_*_sweep_kernel): y = L^-1 b into s->tmp, x = L^-T y into rhs
+        const unsigned nblk = (unsigned)((n + NB - 1) / NB);
+        const int vec = ((((uintptr_t)A) & 15) == 0) && (lda % 2 == 0);
+        HIP_TRY(ctx, hipMemsetAsync(s->d_info + 1, 0, 3 * sizeof(int32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)s->tmp, 0x7FF8A5A5, 2 * (size_t)n, ctx->stream));
+        hipLaunchKernelGGL(trsv_fwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, A, lda, s->winv, rhs,
+                           s->tmp, n, s->d_info, vec);
         LAUNCH_CHECK(ctx);
-    }
-    // backward: L' x = y  (y = s->tmp updated in place left of the block, x written to rhs)
-    const int64_t last = ((n - 1) / NB) * NB;
-    for (int64_t jb = last; jb >= 0; jb -= NB) {
-        const int64_t w = std::min<int64_t>(NB, n - jb);
-        const double* Wrm = s->winv + (jb / NB) * WBLK + NB * NB;
-        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3((unsigned)(1 + jb / NB)), dim3(1024), 0, ctx->stream,
-                           A, lda, Wrm, s->tmp, rhs, jb, (int)w);
+        HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)rhs, 0x7FF8A5A5, 2 * (size_t)n, ctx->stream));
+        hipLaunchKernelGGL(trsv_bwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, A, lda, s->winv,
+                           s->tmp, rhs, n, s->d_info, vec);
         LAUNCH_CHECK(ctx);
     }
     return MADQP_OK;
