@@ -308,6 +308,39 @@ int32_t madqp_mpc_head(madqp_mpc* mpc, madqp_mpc_info* info_host, int32_t* statu
 /* src/solver.jl:288-343; returns MADQP_NUM_NAN for MadNLP.SolveException (src/linear_solver.jl:41-43) */
 int32_t madqp_mpc_body(madqp_mpc* mpc, madqp_mpc_info* info_host);
 
+/* ----------------------------------------- batches of small, equally shaped QPs */
+/* B problems with the same (nx, m) and the same bound / inequality pattern advance in lock step:
+ * assembly and Cholesky are batched launches of the MFMA kernels, the rest of an iteration is one
+ * workgroup per problem; scalars stay on the device, a finished problem is masked out by its status
+ * word (csrc/batch.hip).  Options: madqp_mpc_options with step_rule 0/1 and max_ncorr 0; a failed
+ * factorisation ends that problem (no x100 retry) -- re-solve it with the per-problem driver. */
+#define MADQP_BATCH_SCALARS 16 /* per problem: mu, alpha_p, alpha_d, obj, inf_pr, inf_du, inf_compl, dnorm,
+                                  norm_b, norm_c, del_w, del_c, residual_ratio, reg state (2), spare */
+typedef struct madqp_batch madqp_batch;
+typedef struct madqp_batch_data { /* caller-owned device arrays, problem b at offset b * length; borrowed */
+    const double* H;   /* [B][nx][nx] symmetric, or NULL for LPs */
+    const double* A;   /* [B][m][nx], row k contiguous */
+    const double* q;   /* [B][nx] */
+    const double* rhs; /* [B][m] */
+    const double* c0;  /* [B] */
+    double *x, *xl, *xu, *zl, *zu; /* [B][n], n = nx + ns: iterates after src/solver.jl:131-159 */
+    double* y;                     /* [B][m] */
+} madqp_batch_data;
+/* ind_lb / ind_ub: device, 0-based, shared by all problems; ind_ineq_host: host, strictly increasing */
+int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int64_t m, int64_t ns,
+                           const int64_t* ind_ineq_host, int64_t nlb, const int64_t* ind_lb, int64_t nub,
+                           const int64_t* ind_ub, const madqp_batch_data* data, const madqp_mpc_options* opt,
+                           madqp_batch** out);
+int32_t madqp_batch_destroy(madqp_batch* b);
+/* src/solver.jl:162-179 for every problem: initialize!(kkt), model evaluation, norms, starting point */
+int32_t madqp_batch_init(madqp_batch* b, double mu_init, double bound_fac);
+/* up to max_steps lock-step iterations of mpc! (src/solver.jl:254-345); one 4-byte read-back every
+ * check_every steps; n_active_host: problems still active on return */
+int32_t madqp_batch_iterate(madqp_batch* b, int32_t max_steps, int32_t check_every, int32_t* n_active_host);
+/* per problem: status (0 active, 1 SOLVE_SUCCEEDED, 6 MAXIMUM_ITERATIONS_EXCEEDED,
+ * -3 ERROR_IN_STEP_COMPUTATION, -1 INTERNAL_ERROR), iterations, MADQP_BATCH_SCALARS scalars */
+int32_t madqp_batch_results(madqp_batch* b, int32_t* status_host, int32_t* iters_host, double* scal_host);
+
 #ifdef __cplusplus
 }
 #endif

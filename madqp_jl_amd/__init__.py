@@ -9,6 +9,7 @@ plugin interface: :class:`HIPCondensedKKTSystem` / :class:`HIPCholeskySolver`
 from ._lib import EXPORTED_SYMBOLS, LIB_PATH, MadQPError, load_cdll
 from .backend import HipBackend, State
 from .batch import shard, solve_batch
+from .batched import BatchedMPCSolver
 from .kkt import HIPCholeskySolver, HIPCondensedKKTSystem, HIPNormalKKTSystem
 from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, FixedRegularization,
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
@@ -17,7 +18,7 @@ from .solver import (ERROR_IN_STEP_COMPUTATION, MAXIMUM_ITERATIONS_EXCEEDED, SOL
                      MPCSolver, SolveException)
 
 __all__ = [
-    "HipBackend", "State", "shard", "solve_batch", "HIPCholeskySolver", "HIPCondensedKKTSystem", "HIPNormalKKTSystem", "MPCSolver", "DeviceQP",
+    "HipBackend", "State", "shard", "solve_batch", "BatchedMPCSolver", "HIPCholeskySolver", "HIPCondensedKKTSystem", "HIPNormalKKTSystem", "MPCSolver", "DeviceQP",
     "IPMOptions", "AdaptiveStep", "ConservativeStep", "MehrotraAdaptiveStep", "NoRegularization",
     "FixedRegularization", "AdaptiveRegularization", "MadQPError", "SolveException", "load_cdll",
     "EXPORTED_SYMBOLS", "LIB_PATH", "stream_key", "SOLVE_SUCCEEDED", "MAXIMUM_ITERATIONS_EXCEEDED",

@@ -48,6 +48,16 @@ class CMpcOptions(C.Structure):
                 ("tol_linear_solve", f64)]
 
 
+class CBatchData(C.Structure):
+    """``madqp_batch_data`` of include/madqp.h."""
+
+    _fields_ = [(k, vp) for k in ("H", "A", "q", "rhs", "c0", "x", "xl", "xu", "zl", "zu", "y")]
+
+
+BATCH_SCALARS = ("mu", "alpha_p", "alpha_d", "obj", "inf_pr", "inf_du", "inf_compl", "dnorm", "norm_b", "norm_c",
+                 "del_w", "del_c", "residual_ratio", "reg_p", "reg_d", "spare")
+
+
 class CMpcInfo(C.Structure):
     """``madqp_mpc_info`` of include/madqp.h."""
 
@@ -127,6 +137,12 @@ _SIGNATURES = {
     "madqp_chol_panel_pack": [vp, i64, i64, vp],
     "madqp_chol_panel_unpack": [vp, i64, i64, vp],
     "madqp_chol_factor_end": [vp, pi32],
+    "madqp_batch_create": [vp, i64, i64, i64, i64, pi64, i64, vp, i64, vp, C.POINTER(CBatchData),
+                           C.POINTER(CMpcOptions), C.POINTER(vp)],
+    "madqp_batch_destroy": [vp],
+    "madqp_batch_init": [vp, f64, f64],
+    "madqp_batch_iterate": [vp, i32, i32, pi32],
+    "madqp_batch_results": [vp, pi32, pi32, pf64],
     "madqp_mpc_create": [vp, pstate, vp, vp, vp, vp, f64, f64, f64, C.POINTER(CMpcOptions), C.POINTER(vp)],
     "madqp_mpc_destroy": [vp],
     "madqp_mpc_set_scalars": [vp, f64, f64, f64, f64, i64],

@@ -108,10 +108,23 @@ __device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int
 // is then completed with a unit pivot so that the launch always terminates.
 // Outputs: L_jj in place; Wcm[r + c*NB] = W(r,c) (column-major) and Wrm[c + r*NB] = W(r,c)
 // (row-major), both zero padded to 128 x 128.
+struct Potf2Batch {  // problem blockIdx.x: pointer strides (doubles / ints); skip[b] != 0: leave untouched
+    int64_t sA, sW, sInfo;
+    const int32_t* skip;
+};
 __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int nb,
                                                         double* __restrict__ Wcm,
                                                         double* __restrict__ Wrm,
-                                                        int32_t* __restrict__ info, int32_t col0) {
+                                                        int32_t* __restrict__ info, int32_t col0,
+                                                        Potf2Batch bt) {
+    if (gridDim.x > 1 || bt.skip) {
+        const int64_t b = blockIdx.x;
+        if (bt.skip && bt.skip[b] != 0) return;
+        A += b * bt.sA;
+        Wcm += b * bt.sW;
+        Wrm += b * bt.sW;
+        info += b * bt.sInfo;
+    }
     __shared__ double S[NB * LDS_LD];           // S[c*LDS_LD + r] = element (r, c)
     __shared__ double Wd[NSB * SB * WD_LD];     // inverse diagonal sub-blocks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -561,7 +574,7 @@ static int32_t factor_block(madqp_chol* s, double* A, int64_t lda, int64_t jb, i
     {
         ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
         hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, ctx->stream, A + jb + jb * lda, lda,
-                           (int)w, Wcm, Wrm, s->d_info, (int32_t)jb);
+                           (int)w, Wcm, Wrm, s->d_info, (int32_t)jb, Potf2Batch{0, 0, 0, nullptr});
         LAUNCH_CHECK(ctx);
     }
     if (jb + w < n) {
@@ -630,6 +643,96 @@ extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int3
     *info_host = info;
     s->factored = (info == 0);
     return MADQP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same recursive factorisation for a batch of B equally sized matrices at fixed strides (small
+// QPs, batch.hip): every launch covers all problems (grid.y / grid.x = problem), problems with
+// skip[b] != 0 are left alone.  winv: B x nblk x WBLK, info: B ints.
+namespace {
+struct CholBatch {
+    madqp_ctx* ctx;
+    double* A;
+    int64_t lda, n, sA;
+    double* winv;
+    int64_t sW;
+    int32_t* info;
+    int64_t B;
+    const int32_t* skip;
+};
+int32_t bfactor_update(const CholBatch& c, int64_t row0, int64_t k0, int64_t width) {
+    GemmArgs g{};
+    g.X = c.A + row0 + k0 * c.lda;
+    g.ldx = c.lda;
+    g.Y = g.X;
+    g.ldy = c.lda;
+    g.C = c.A + row0 + row0 * c.lda;
+    g.ldc = c.lda;
+    g.Cin = g.C;
+    g.ldcin = c.lda;
+    g.alpha = -1.0;
+    g.beta = 1.0;
+    g.M = c.n - row0;
+    g.N = width;
+    g.K = row0 - k0;
+    const int64_t npad = (c.n + NB - 1) / NB * NB;
+    if (c.lda >= npad) {
+        g.Mread = npad - row0;
+        g.Nread = std::min<int64_t>(npad - row0, (width + NB - 1) / NB * NB);
+    }
+    g.lower_only = 1;
+    GemmBatch bt{c.B, c.sA, c.sA, c.sA, c.sA, 0, c.skip};
+    return madqp_gemm_tn(c.ctx, g, MADQP_PROF_POTRF_GEMM, nullptr, 0, &bt);
+}
+int32_t bfactor_block(const CholBatch& c, int64_t jb, int64_t w) {
+    madqp_ctx* ctx = c.ctx;
+    double* Wcm = c.winv + (jb / NB) * WBLK;
+    {
+        ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
+        hipLaunchKernelGGL(potf2_inv_kernel, dim3((unsigned)c.B), dim3(256), 0, ctx->stream,
+                           c.A + jb + jb * c.lda, c.lda, (int)w, Wcm, Wcm + NB * NB, c.info, (int32_t)jb,
+                           Potf2Batch{c.sA, c.sW, 1, c.skip});
+        LAUNCH_CHECK(ctx);
+    }
+    if (jb + w < c.n) {
+        GemmArgs g{};
+        g.X = c.A + (jb + w) + jb * c.lda;
+        g.ldx = c.lda;
+        g.Y = Wcm;
+        g.ldy = NB;
+        g.C = c.A + (jb + w) + jb * c.lda;
+        g.ldc = c.lda;
+        g.alpha = 1.0;
+        g.beta = 0.0;
+        g.M = c.n - jb - w;
+        g.N = w;
+        g.K = w;
+        const int64_t npad = (c.n + NB - 1) / NB * NB;
+        if (c.lda >= npad) g.Mread = npad - jb - w;
+        g.Nread = NB;
+        GemmBatch bt{c.B, c.sA, c.sW, c.sA, 0, 0, c.skip};
+        return madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_TRSM, nullptr, 0, &bt);
+    }
+    return MADQP_OK;
+}
+int32_t bfactor_range(const CholBatch& c, int64_t j0, int64_t w) {
+    if (w <= NB) return bfactor_block(c, j0, w);
+    const int64_t h = ((w + NB - 1) / NB + 1) / 2 * NB;
+    int32_t r = bfactor_range(c, j0, h);
+    if (r) return r;
+    if ((r = bfactor_update(c, j0 + h, j0, w - h))) return r;
+    return bfactor_range(c, j0 + h, w - h);
+}
+}  // namespace
+
+// internal (batch.hip): asynchronous; info[b] = 0 or the first failing column of problem b (1-based)
+int32_t madqp_chol_factor_batched(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t sA, double* winv,
+                                  int64_t sW, int32_t* info, int64_t B, const int32_t* skip) {
+    ARG_TRY(ctx, A && winv && info && lda >= n && B >= 1);
+    if (n == 0) return MADQP_OK;
+    HIP_TRY(ctx, hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), ctx->stream));
+    CholBatch c{ctx, A, lda, n, sA, winv, sW, info, B, skip};
+    return bfactor_range(c, 0, n);
 }
 
 // ---------------------------------------------------------------------------------------------

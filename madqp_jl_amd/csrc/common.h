@@ -106,10 +106,21 @@ struct GemmArgs {
 // cols: optional host list of ncols column ranges [cols[2r], cols[2r+1]) (multiples of 128 relative to
 // C) -- only output tiles whose columns fall in one of them are computed (multi-GPU path: the block
 // columns a rank owns, in ONE launch)
+// batch: optional -- the same product for B problems laid out at fixed strides (doubles) from the
+// pointers of `a` (grid.y = problem); problems with skip[b] != 0 are left untouched
+struct GemmBatch {
+    int64_t B;
+    int64_t sX, sY, sC, sCin, sD;
+    const int32_t* skip;
+};
 int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int64_t* cols = nullptr,
-                      int64_t ncols = 0);
+                      int64_t ncols = 0, const GemmBatch* batch = nullptr);
 
 void madqp_gemm_release_tables(madqp_ctx* ctx);
+
+// chol.hip: recursive blocked factorisation of B equally sized matrices (see there)
+int32_t madqp_chol_factor_batched(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t sA, double* winv,
+                                  int64_t sW, int32_t* info, int64_t B, const int32_t* skip);
 
 // gemv.hip (internal entry with explicit class)
 int32_t madqp_gemv_impl(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t cols, double alpha,

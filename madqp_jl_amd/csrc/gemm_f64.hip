@@ -51,6 +51,7 @@ struct KArgs {
     int32_t ntiles;
     int32_t fast_ok;  // pointers / leading dimensions allow 16-byte loads
     int32_t xcd_remap;
+    GemmBatch batch;  // B <= 1: single problem
 #ifdef MADQP_STAMPS
     unsigned long long* stamps;  // diagnostic build only (tools/gemm_probe): per-workgroup clocks
 #endif
@@ -275,7 +276,16 @@ __device__ __forceinline__ void mainloop_dma(const GemmArgs& g, int64_t i0, int6
 
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_DOUBLES];
-    const GemmArgs& g = ka.g;
+    GemmArgs g = ka.g;
+    if (ka.batch.B > 1) {  // wave-uniform pointer offsets of problem blockIdx.y
+        const int64_t b = blockIdx.y;
+        if (ka.batch.skip && ka.batch.skip[b] != 0) return;
+        g.X += b * ka.batch.sX;
+        g.Y += b * ka.batch.sY;
+        g.C += b * ka.batch.sC;
+        if (g.Cin) g.Cin += b * ka.batch.sCin;
+        if (g.dvec) g.dvec += b * ka.batch.sD;
+    }
     // Tile selection: the table is cut into 8 contiguous chunks, one per XCD (workgroup ids equal
     // mod 8 share an XCD under the observed round-robin dispatch; claiming tiles by the real
     // HW_REG_XCC_ID gave the same traffic and time, so the static map is kept).  Speed only: any
@@ -380,7 +390,8 @@ void madqp_gemm_release_tables(madqp_ctx* ctx) {
     for (auto& kv : mine) (void)hipFree(kv.second.d);
 }
 
-int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int64_t* cols, int64_t ncols) {
+int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int64_t* cols, int64_t ncols,
+                      const GemmBatch* batch) {
     ARG_TRY(ctx, a.M >= 0 && a.N >= 0 && a.K >= 0 && a.X && a.Y && a.C);
     if (a.M == 0 || a.N == 0) return MADQP_OK;
     const int64_t tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -450,6 +461,9 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
     ka.ntiles = it->second.n;
     static const int xcd_remap = getenv("MADQP_GEMM_XCD") ? atoi(getenv("MADQP_GEMM_XCD")) : 1;
     ka.xcd_remap = xcd_remap;
+    ka.batch = batch ? *batch : GemmBatch{1, 0, 0, 0, 0, 0, nullptr};
+    const unsigned gy = (unsigned)std::max<int64_t>(1, ka.batch.B);
+    ARG_TRY(ctx, gy <= 65535);
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     ka.fast_ok = al16(a.X) && al16(a.Y) && (a.ldx % 2 == 0) && (a.ldy % 2 == 0);
 #ifdef MADQP_STAMPS
@@ -471,7 +485,7 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
         if (total - off - cnt < seg / 4) cnt = total - off;  // no tiny last segment
         ka.table = table0 + off;
         ka.ntiles = (int32_t)cnt;
-        hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3(ka.ntiles), dim3(NTHREADS), 0, ctx->stream, ka);
+        hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3(ka.ntiles, gy), dim3(NTHREADS), 0, ctx->stream, ka);
         LAUNCH_CHECK(ctx);
         if (cnt == total - off) break;
     }

@@ -42,181 +42,15 @@ struct madqp_kkt {
 };
 
 namespace {
+#define MQ_KERNEL __global__ __launch_bounds__(TPB) void
+#define MQ_BLOCK blockIdx.x
 #define GRID_STRIDE(i, len) \
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < (len); i += (int64_t)gridDim.x * TPB)
 inline int grid_for(int64_t len) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((len + TPB - 1) / TPB, MADQP_MAX_BLOCKS));
 }
 
-__global__ __launch_bounds__(TPB) void theta_kernel(int64_t m, int64_t nx,
-                                                    const int64_t* __restrict__ slot,
-                                                    const double* __restrict__ pr_diag,
-                                                    const double* __restrict__ du_diag,
-                                                    double* __restrict__ theta) {
-    GRID_STRIDE(i, m) {
-        const int64_t k = slot[i];
-        if (k >= 0) {
-            const double S = pr_diag[nx + k];
-            theta[i] = S / (1.0 - du_diag[i] * S);
-        } else {
-            theta[i] = -1.0 / du_diag[i];
-        }
-    }
-}
-
-// t = r2 + r1_s / S ;  u = theta * t
-__global__ __launch_bounds__(TPB) void condense_kernel(int64_t m, int64_t nx,
-                                                       const int64_t* __restrict__ slot,
-                                                       const double* __restrict__ pr_diag,
-                                                       const double* __restrict__ theta,
-                                                       const double* __restrict__ wx,
-                                                       const double* __restrict__ wy,
-                                                       double* __restrict__ t, double* __restrict__ u) {
-    GRID_STRIDE(i, m) {
-        const int64_t k = slot[i];
-        double ti = wy[i];
-        if (k >= 0) ti += wx[nx + k] / pr_diag[nx + k];
-        t[i] = ti;
-        u[i] = theta[i] * ti;
-    }
-}
-
-// dy = theta (u - t), ds = (r1_s + dy) / S       (u holds A dx on entry)
-__global__ __launch_bounds__(TPB) void decondense_kernel(int64_t m, int64_t nx,
-                                                         const int64_t* __restrict__ slot,
-                                                         const double* __restrict__ pr_diag,
-                                                         const double* __restrict__ theta,
-                                                         const double* __restrict__ t,
-                                                         const double* __restrict__ u,
-                                                         double* __restrict__ wx, double* __restrict__ wy) {
-    GRID_STRIDE(i, m) {
-        const int64_t k = slot[i];
-        const double dy = theta[i] * (u[i] - t[i]);
-        wy[i] = dy;
-        if (k >= 0) wx[nx + k] = (wx[nx + k] + dy) / pr_diag[nx + k];
-    }
-}
-
-__global__ __launch_bounds__(TPB) void jt_slack_kernel(int64_t ns, const int64_t* __restrict__ ind,
-                                                       const double* __restrict__ y,
-                                                       double* __restrict__ out_s, double alpha,
-                                                       double beta) {
-    GRID_STRIDE(k, ns) {
-        const double v = alpha * (-y[ind[k]]);
-        out_s[k] = (beta == 0.0) ? v : v + beta * out_s[k];
-    }
-}
-
-// wy_i = alpha (u_i - vx_s[slot]) + beta wy_i
-__global__ __launch_bounds__(TPB) void mul_rows_kernel(int64_t m, const int64_t* __restrict__ slot,
-                                                       const double* __restrict__ u,
-                                                       const double* __restrict__ vx_s,
-                                                       double* __restrict__ wy, double alpha,
-                                                       double beta) {
-    GRID_STRIDE(i, m) {
-        const int64_t k = slot[i];
-        double a = u[i];
-        if (k >= 0) a -= vx_s[k];
-        wy[i] = (beta == 0.0) ? alpha * a : alpha * a + beta * wy[i];
-    }
-}
-
-// f <- Hx + q (first nx), 0 (slacks);  partial sums of q'x and x'Hx
-__global__ __launch_bounds__(TPB) void eval_grad_kernel(int64_t n, int64_t nx, int has_h,
-                                                        const double* __restrict__ q,
-                                                        const double* __restrict__ x,
-                                                        double* __restrict__ f,
-                                                        double* __restrict__ part) {
-    __shared__ double sm[TPB / 64];
-    double s1 = 0.0, s2 = 0.0;
-    GRID_STRIDE(i, n) {
-        if (i < nx) {
-            const double hx = has_h ? f[i] : 0.0;
-            const double xi = x[i];
-            s1 += q[i] * xi;
-            s2 += xi * hx;
-            f[i] = hx + q[i];
-        } else {
-            f[i] = 0.0;
-        }
-    }
-    for (int which = 0; which < 2; ++which) {
-        double v = which ? s2 : s1;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) part[blockIdx.x * 2 + which] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-    }
-}
-__global__ __launch_bounds__(TPB) void sum2_final_kernel(const double* __restrict__ part, int nblocks,
-                                                         double* __restrict__ res) {
-    __shared__ double sm[TPB / 64];
-    for (int which = 0; which < 2; ++which) {
-        double v = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += TPB) v += part[b * 2 + which];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) res[which] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-    }
-}
-
-// c_i = (u_i - s_slot) - rhs_i
-__global__ __launch_bounds__(TPB) void eval_cons_kernel(int64_t m, const int64_t* __restrict__ slot,
-                                                        const double* __restrict__ xs,
-                                                        const double* __restrict__ rhs,
-                                                        double* __restrict__ c) {
-    GRID_STRIDE(i, m) {
-        const int64_t k = slot[i];
-        double a = c[i];
-        if (k >= 0) a -= xs[k];
-        c[i] = a - rhs[i];
-    }
-}
-
-// ---- normal-equations mode (src/KKT/normalkkt.jl) ----
-// D = 1 / Sigma (normalkkt.jl:177) for all n entries
-__global__ __launch_bounds__(TPB) void recip_kernel(int64_t n, const double* __restrict__ pr_diag,
-                                                    double* __restrict__ d) {
-    GRID_STRIDE(i, n) d[i] = 1.0 / pr_diag[i];
-}
-// diagonal contribution of the slack columns (-1 entries): D_s on inequality rows, 0 on equality rows
-__global__ __launch_bounds__(TPB) void slack_diag_kernel(int64_t m, int64_t nx,
-                                                         const int64_t* __restrict__ slot,
-                                                         const double* __restrict__ d,
-                                                         double* __restrict__ out) {
-    GRID_STRIDE(i, m) {
-        const int64_t k = slot[i];
-        out[i] = (k >= 0) ? d[nx + k] : 0.0;
-    }
-}
-// r1 = wx / Sigma (normalkkt.jl:192)
-__global__ __launch_bounds__(TPB) void div_kernel(int64_t n, const double* __restrict__ a,
-                                                  const double* __restrict__ b, double* __restrict__ out) {
-    GRID_STRIDE(i, n) out[i] = a[i] / b[i];
-}
-// r2_i = (u_i - r1_s[slot]) - wy_i   (A_full r1 - r2, normalkkt.jl:193-194)
-__global__ __launch_bounds__(TPB) void normal_rhs_kernel(int64_t m, const int64_t* __restrict__ slot,
-                                                         const double* __restrict__ u,
-                                                         const double* __restrict__ r1s,
-                                                         const double* wy, double* out) {
-    GRID_STRIDE(i, m) {  // out may alias wy (elementwise)
-        const int64_t k = slot[i];
-        double a = u[i];
-        if (k >= 0) a -= r1s[k];
-        out[i] = a - wy[i];
-    }
-}
-// wx = (wx - t) / Sigma   (normalkkt.jl:199-201)
-__global__ __launch_bounds__(TPB) void normal_back_kernel(int64_t n, const double* __restrict__ t,
-                                                          const double* __restrict__ pr_diag,
-                                                          double* __restrict__ wx) {
-    GRID_STRIDE(i, n) wx[i] = (wx[i] - t[i]) / pr_diag[i];
-}
+#include "kkt_kernels.inc"
 }  // namespace
 
 #define KLAUNCH(kern, len, ...)                                                                 \

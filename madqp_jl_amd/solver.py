@@ -59,6 +59,28 @@ def _push_interior(x, l, u, bound_push, bound_fac):
     return out
 
 
+def native_options(opt) -> CMpcOptions:
+    """``madqp_mpc_options`` (include/madqp.h) of an :class:`IPMOptions`."""
+    rule, reg = opt.step_rule, opt.regularization
+    c = CMpcOptions(tol=opt.tol, max_iter=opt.max_iter, max_ncorr=opt.max_ncorr, mu_min=opt.mu_min,
+                    check_residual=int(bool(opt.check_residual)), tol_linear_solve=opt.tol_linear_solve)
+    if isinstance(rule, ConservativeStep):
+        c.step_rule, c.step_param = 0, rule.tau
+    elif isinstance(rule, AdaptiveStep):
+        c.step_rule, c.step_param = 1, rule.tau_min
+    elif isinstance(rule, MehrotraAdaptiveStep):
+        c.step_rule, c.step_param = 2, rule.gamma_f
+    else:
+        raise TypeError(rule)
+    if isinstance(reg, NoRegularization):
+        c.regularization = 0
+    elif isinstance(reg, FixedRegularization):
+        c.regularization, c.delta_p, c.delta_d = 1, reg.delta_p, reg.delta_d
+    else:
+        c.regularization, c.delta_p, c.delta_d, c.delta_min = 2, reg.delta_p, reg.delta_d, reg.delta_min
+    return c
+
+
 class MPCSolver:
     """``MPCSolver(nlp; opts...)`` (src/structure.jl:77-176) for a :class:`DeviceQP`."""
 
@@ -103,33 +125,12 @@ class MPCSolver:
         self._info = CMpcInfo()
 
     # ---- driver="native": the loop body runs in csrc/mpc.hip, one foreign call per iteration ----
-    def _native_options(self) -> CMpcOptions:
-        opt, rule, reg = self.opt, self.opt.step_rule, self.opt.regularization
-        c = CMpcOptions(tol=opt.tol, max_iter=opt.max_iter, max_ncorr=opt.max_ncorr, mu_min=opt.mu_min,
-                        check_residual=int(bool(opt.check_residual)),
-                        tol_linear_solve=opt.tol_linear_solve)
-        if isinstance(rule, ConservativeStep):
-            c.step_rule, c.step_param = 0, rule.tau
-        elif isinstance(rule, AdaptiveStep):
-            c.step_rule, c.step_param = 1, rule.tau_min
-        elif isinstance(rule, MehrotraAdaptiveStep):
-            c.step_rule, c.step_param = 2, rule.gamma_f
-        else:
-            raise TypeError(rule)
-        if isinstance(reg, NoRegularization):
-            c.regularization = 0
-        elif isinstance(reg, FixedRegularization):
-            c.regularization, c.delta_p, c.delta_d = 1, reg.delta_p, reg.delta_d
-        else:
-            c.regularization, c.delta_p, c.delta_d, c.delta_min = 2, reg.delta_p, reg.delta_d, reg.delta_min
-        return c
-
     def _native_open(self):
         self._native_close()
         st = self.st
         self._native = self.be.mpc_create(self.kkt._h, st, st.w1, st.w2, self.q, st.rhs,
                                           self.obj_scale * self.qp.c0, self.norm_b, self.norm_c,
-                                          self._native_options())
+                                          native_options(self.opt))
         self.be.mpc_set_scalars(self._native, self.mu, self.del_w, self.del_c, self.obj_val, self.k)
 
     def _native_close(self):

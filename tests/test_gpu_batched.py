@@ -1,0 +1,98 @@
+"""GPU: the lock-step batched driver (csrc/batch.hip, BASELINE configs[3]) against the CPU oracle, problem by
+problem: same status, same iteration count, solution / objective / multipliers within the tolerance of
+test_gpu_solver.py.  Problems of one batch converge at different iterations (status mask), one may fail
+without disturbing the others, the order of the problems does not matter."""
+import numpy as np
+import pytest
+import torch
+
+import madqp_jl_amd as M
+from oracle import mpc
+from oracle import qp as Q
+
+pytestmark = pytest.mark.gpu
+REG = M.FixedRegularization(1e-8, -1e-8)
+OREG = mpc.FixedRegularization(1e-8, -1e-8)
+
+
+def to_device(qp, be):
+    return M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
+
+
+def close(a, b, tol):
+    return abs(a - b) <= tol * max(1.0, abs(a), abs(b))
+
+
+def check_against_oracle(qps, res, **okw):
+    for i, (qp, r) in enumerate(zip(qps, res)):
+        ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG, **okw)
+        assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED, (i, r["status"], ref["status"])
+        assert r["iter"] == ref["iter"], (i, r["iter"], ref["iter"])
+        assert close(r["objective"], ref["objective"], 1e-9), (i, r["objective"], ref["objective"])
+        assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+        assert np.max(np.abs(r["multipliers"] - ref["multipliers"])) <= 1e-6
+        t = ref["trace"][-1]
+        assert close(r["inf_pr"], t["inf_pr"], 1e-6) and close(r["inf_du"], t["inf_du"], 1e-6)
+
+
+@pytest.mark.parametrize("n,m,B,family", [(64, 24, 12, "wigner"), (40, 16, 6, "lp"), (300, 120, 5, "wigner"),
+                                          (130, 1, 3, "wigner")])
+def test_batched_vs_oracle(hip, n, m, B, family):
+    qps = [Q.synthetic_qp(500 + 7 * i + n, n, m, family) for i in range(B)]
+    s = M.BatchedMPCSolver([to_device(q, hip) for q in qps], hip, regularization=REG)
+    res = s.solve()
+    s.close()
+    assert len({r["iter"] for r in res}) > 1 or B < 4  # the mask is exercised: different iteration counts
+    check_against_oracle(qps, res)
+
+
+def test_batched_equality_rows_and_step_rule(hip):
+    qps = []
+    for i in range(6):
+        qp = Q.synthetic_qp(900 + i, 48, 20)
+        qp.lcon[[2, 7]] = qp.ucon[[2, 7]] = 0.25  # equality rows: Theta = -1/delta_d
+        qps.append(qp)
+    s = M.BatchedMPCSolver([to_device(q, hip) for q in qps], hip, regularization=REG,
+                           step_rule=M.ConservativeStep(0.99))
+    res = s.solve(check_every=3)
+    s.close()
+    check_against_oracle(qps, res, step_rule=mpc.ConservativeStep(0.99))
+    with pytest.raises(ValueError):  # default delta_d = 0 with equality rows
+        M.BatchedMPCSolver([to_device(q, hip) for q in qps], hip)
+
+
+def test_batched_is_the_per_problem_driver(hip):
+    """Same library, two drivers: the batch and MPCSolver agree problem by problem; a problem that
+    breaks down (indefinite H) ends with an error status and leaves the others untouched; a permuted
+    batch gives the permuted results bit for bit."""
+    qps = [Q.synthetic_qp(700 + i, 96, 40) for i in range(8)]
+    bad = 3
+    qps[bad].H = qps[bad].H - 1e6 * np.eye(96)
+    dq = [to_device(q, hip) for q in qps]
+    s = M.BatchedMPCSolver(dq, hip, regularization=REG)
+    res = s.solve()
+    s.close()
+    assert res[bad]["status"] in (M.ERROR_IN_STEP_COMPUTATION, -1)
+    for i, r in enumerate(res):
+        if i == bad:
+            continue
+        one = M.MPCSolver(dq[i], hip, regularization=REG)
+        ref = one.solve()
+        one.close()
+        assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
+        assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-8
+    perm = [5, 0, 7, 2, 1, 6, 4]
+    s2 = M.BatchedMPCSolver([dq[i] for i in perm], hip, regularization=REG)
+    res2 = s2.solve()
+    s2.close()
+    for k, i in enumerate(perm):
+        assert res2[k]["iter"] == res[i]["iter"] and np.array_equal(res2[k]["solution"], res[i]["solution"])
+
+
+def test_batched_rejects_mixed_patterns(hip):
+    a, b = Q.synthetic_qp(1, 20, 8), Q.synthetic_qp(2, 20, 8)
+    b.uvar[3] = np.inf
+    with pytest.raises(ValueError):
+        M.BatchedMPCSolver([to_device(a, hip), to_device(b, hip)], hip, regularization=REG)
+    with pytest.raises(ValueError):
+        M.BatchedMPCSolver([to_device(a, hip)], hip, regularization=REG, max_ncorr=2)

