@@ -126,27 +126,40 @@ __device__ __forceinline__ Prob prob_of(const BQ& q, int64_t b) {
 __device__ void wg_gemv_n(int64_t rows, int64_t cols, double alpha, const double* __restrict__ M,
                           const double* __restrict__ x, double beta, double* __restrict__ y) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t k = wave; k < rows; k += TPB / 64) {
-        const double* row = M + k * cols;
-        double acc = 0.0;
-        for (int64_t j = lane; j < cols; j += 64) acc += row[j] * x[j];
+    constexpr int NW = TPB / 64, R = 4;  // 4 rows per wave pass: 4x the loads in flight
+    for (int64_t k0 = (int64_t)wave * R; k0 < rows; k0 += NW * R) {
+        double acc[R];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) y[k] = (beta == 0.0) ? alpha * acc : alpha * acc + beta * y[k];
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        for (int64_t j = lane; j < cols; j += 64) {
+            const double xj = x[j];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (k0 + r < rows) acc[r] += M[(k0 + r) * cols + j] * xj;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double a = acc[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0 && k0 + r < rows) y[k0 + r] = (beta == 0.0) ? alpha * a : alpha * a + beta * y[k0 + r];
+        }
     }
 }
 // out(cols) = alpha * M' v + beta * out,  M row-major rows x cols: a thread per column
 __device__ void wg_gemv_t(int64_t rows, int64_t cols, double alpha, const double* __restrict__ M,
                           const double* __restrict__ v, double beta, double* __restrict__ out) {
     for (int64_t j = threadIdx.x; j < cols; j += TPB) {
-        double a0 = 0.0, a1 = 0.0;
+        double a[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[r] = 0.0;
         int64_t k = 0;
-        for (; k + 1 < rows; k += 2) {
-            a0 += M[k * cols + j] * v[k];
-            a1 += M[(k + 1) * cols + j] * v[k + 1];
+        for (; k + 8 <= rows; k += 8) {  // 8 independent loads in flight per thread
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[r] += M[(k + r) * cols + j] * v[k + r];
         }
-        if (k < rows) a0 += M[k * cols + j] * v[k];
-        const double acc = a0 + a1;
+        for (; k < rows; ++k) a[0] += M[k * cols + j] * v[k];
+        const double acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         out[j] = (beta == 0.0) ? alpha * acc : alpha * acc + beta * out[j];
     }
 }

@@ -29,6 +29,7 @@ def main():
                    help="batched: lock-step engine of csrc/batch.hip; streams: one MPCSolver per problem, "
                         "several HIP streams in flight (madqp_jl_amd/batch.py)")
     p.add_argument("--check-every", type=int, default=2)
+    p.add_argument("--profile", action="store_true", help="print ms / launches per kernel class (perturbs timing)")
     a = p.parse_args()
     import torch
 
@@ -55,12 +56,17 @@ def main():
         warm.solve()
         warm.close()
         solver = M.BatchedMPCSolver(qps, be, **opts)
+        if a.profile:
+            be.prof_enable(M._lib.PROF_CLASSES)
+            be.prof_reset()
         bench.dist_barrier(world)
         t0 = time.perf_counter()
         res = solver.solve(check_every=a.check_every)  # set-up (scaling, start point) + all iterations + read-back
         bench.dist_barrier(world)
         dt = bench.max_over_ranks(time.perf_counter() - t0, world, torch.device("cuda", local_rank))
         lockstep = int(max(r["iter"] for r in res))
+        if a.profile and rank == 0:
+            print({k: (round(v[0], 2), v[1]) for k, v in be.prof_get().items() if v[1]}, flush=True)
         solver.close()
     iters = sum(r["iter"] for r in res)
     ok = sum(r["status"] == M.SOLVE_SUCCEEDED for r in res)
