@@ -25,7 +25,7 @@ def rows(kind):
 
 def short(name):
     for k in ("gemm_tn_f64_kernel", "potf2_inv_kernel", "gemv_n_wave", "gemv_n_block", "gemv_t_kernel",
-              "trsv_diag_fwd", "trsv_diag_bwd", "scale_rows_kernel"):
+              "trsv_fwd_sweep_kernel", "trsv_bwd_sweep_kernel", "scale_rows_kernel"):
         if k in name:
             return k
     return None
@@ -77,6 +77,26 @@ if big:
         / max(big.get("sq", {}).get("ms", 1) * 1e-3 * 2.385e9, 1))
 nx = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+# HBM-bound kernels: achieved rate = PMC bytes (read corrected + written) / duration of the same dispatches
+# in the un-instrumented --kernel-trace --stats pass (average duration x dispatch count)
+stats = {}
+for f in glob.glob(f"gpurun_out/prof_{tag}_stats/*/*_kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Name"])
+        if k:
+            stats[k] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) * 1e-3)
+rates = {}
+for k in ("trsv_fwd_sweep_kernel", "trsv_bwd_sweep_kernel", "gemv_n_wave", "gemv_t_kernel", "scale_rows_kernel"):
+    if k in out and k in stats and "hbm_read_GB_corrected" in out[k]:
+        gb = out[k]["hbm_read_GB_corrected"] + out[k].get("hbm_write_GB", 0.0)
+        per_launch = gb / max(out[k]["dispatches"], 1)
+        e = dict(avg_us=round(stats[k]["avg_us"], 1), hbm_GB_per_launch=round(per_launch, 3),
+                 achieved_TB_per_s=round(per_launch / (stats[k]["avg_us"] * 1e-6) / 1e3, 2),
+                 frac_of_8_TB_per_s=round(per_launch / (stats[k]["avg_us"] * 1e-6) / 8e3, 3))
+        if k.startswith("trsv"):
+            e["algorithmic_GB_per_launch"] = round(4.0 * nx * nx / 1e9, 3)  # half of L, 8 B per entry
+        rates[k] = e
+out["hbm_bound_kernels"] = rates
 out["config"] = dict(nx=nx, m=m, command=f"rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --nx {nx} --m {m}")
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 for f in glob.glob(f"gpurun_out/prof_{tag}_stats/*/*_kernel_stats.csv"):
