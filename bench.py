@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--no-distributed-extra", action="store_true",
                    help="N > 1: skip the additional strong-scaling measurement of the distributed KKT path")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-nx", type=int, default=6000)
+    p.add_argument("--cpu-sample-nx", type=int, default=8000)
     p.add_argument("--profile-all", action="store_true", help="time every kernel class (perturbs the "
                    "launch-bound ones); default times only the MFMA classes")
     return p.parse_args()
@@ -68,29 +68,40 @@ def cpu_baseline(args, nx, m):
         threadpool_limits(limits=cores)
     except Exception:
         pass
-    sn = min(args.cpu_sample_nx, nx)
-    sm = max(1, int(round(sn * m / nx)))
-    qp = Q.synthetic_qp(args.seed, sn, sm)
-    s = mpc.MPCSolver(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8),
-                      step_rule=mpc.AdaptiveStep(0.995), mu_min=1e-12, max_iter=300, max_ncorr=args.max_ncorr)
-    s.initialize()
-    s.iteration_head()
-    s.iteration_body()  # warm-up
-    iters, t0 = 0, time.perf_counter()
-    while iters < 3 or (time.perf_counter() - t0 < 10.0 and iters < 50):
-        if s.iteration_head() is not None:
-            break
-        s.iteration_body()
-        iters += 1
-    dt = time.perf_counter() - t0
-    flops = lambda a, b: b * a * a + a ** 3 / 3.0
-    scale = flops(sn, sm) / flops(nx, m)
-    return dict(
+    def sample(sn, budget_s, max_iters):
+        sm = max(1, int(round(sn * m / nx)))
+        qp = Q.synthetic_qp(args.seed, sn, sm)
+        s = mpc.MPCSolver(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8),
+                          step_rule=mpc.AdaptiveStep(0.995), mu_min=1e-12, max_iter=300, max_ncorr=args.max_ncorr)
+        s.initialize()
+        s.iteration_head()
+        s.iteration_body()  # warm-up
+        iters, t0 = 0, time.perf_counter()
+        while iters < 3 or (time.perf_counter() - t0 < budget_s and iters < max_iters):
+            if s.iteration_head() is not None:
+                break
+            s.iteration_body()
+            iters += 1
+        dt = time.perf_counter() - t0
+        flops = lambda a, b: b * a * a + a ** 3 / 3.0
+        return sn, sm, iters, dt, flops(sn, sm) / flops(nx, m)
+
+    sn, sm, iters, dt, scale = sample(min(args.cpu_sample_nx, nx), 12.0, 50)
+    out = dict(
         value=(iters / dt) * scale, unit="IPM iterations/s", cores=cores, kind="port",
         sample=(f"oracle/mpc.py (numpy+scipy LAPACK, {cores} BLAS threads = the box's CPU share) on the same synthetic "
                 f"family at nx={sn}, m={sm}: {iters} iterations in {dt:.2f} s = {iters / dt:.3f} it/s, "
                 f"scaled by the flop ratio (m nx^2 + nx^3/3) {scale:.3e} to nx={nx}, m={m}"),
         measured_it_per_s_at_sample=iters / dt, sample_nx=sn, sample_m=sm)
+    try:  # per-core normalisation (the reference's CPU solver is single threaded)
+        threadpool_limits(limits=1)
+        sn1, sm1, it1, dt1, sc1 = sample(min(2500, nx), 4.0, 20)
+        out["single_thread"] = dict(value=(it1 / dt1) * sc1, cores=1,
+                                    sample=f"nx={sn1}, m={sm1}: {it1} iterations in {dt1:.2f} s, flop-scaled {sc1:.3e}")
+        threadpool_limits(limits=cores)
+    except Exception as e:
+        out["single_thread"] = {"error": str(e)[:200]}
+    return out
 
 
 def pmc_traffic(nx, m):
