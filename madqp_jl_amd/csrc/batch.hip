@@ -752,7 +752,7 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
     BALLOC(q.u, B * m);
     BALLOC(q.K, B * q.ldk * q.ldk + 128, true);
     BALLOC(q.S, B * q.kpad * q.npad);
-    BALLOC(q.winv, B * q.nblk * WBLK);
+    BALLOC(q.winv, B * q.nblk * WBLK, true);  // potf2_inv_kernel writes the lower parts only
     BALLOC(q.tmp, B * q.npad);
     BALLOC(q.scal, B * S_COUNT, true);
     BALLOC(q.status, B, true);

@@ -40,58 +40,70 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// One wave: Cholesky of the 16 x 16 sub-block at (b, b) of S and the inverse of its factor.
-// Lane r (= lane & 15) keeps row r of the sub-block in registers; column k is broadcast with
-// v_readlane, so the 16 elimination steps need no LDS round trip and no barrier.
-// Writes L (lower) back to S and W = L^-1 to Wd[r*WD_LD + c] (zero above the diagonal).
+// 1/sqrt(a) for a normal, positive pivot: hardware estimate (v_rsq_f64, ~2^-26) + two coupled
+// Goldschmidt steps in fma form -- ~10 dependent instructions on the 16-step critical chain instead of
+// the sqrt-and-divide sequence behind rsqrt().  Relative error ~1e-16.
+__device__ __forceinline__ double fast_rsqrt(double a) {
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    h = __builtin_fma(h, r, h);
+    return h + h;
+}
+
+// One wave: Cholesky of the 16 x 16 sub-block at (b, b) of S and the inverse of its factor, as 16
+// rank-1 steps on the MFMA unit.  The (symmetric) sub-block and W live in the accumulator layout of
+// v_mfma_f64_16x16x4_f64 (lane l, register v: row (l>>4) + 4v, column l&15).  Row k of the block
+// therefore sits in register k>>2 of the 16 lanes of group g = k&3 -- exactly the lanes that feed
+// k-slot g of BOTH operands -- so the scaled row (= column l_k, by symmetry) is the A- and the
+// B-operand of  D -= l_k l_k'  as it stands: no cross-lane traffic except one v_readlane for the
+// pivot.  W = L^-1 follows from the same steps applied to the identity (W[k,:] *= 1/l_kk,
+// W[i,:] -= l_ik W[k,:], i > k), a second MFMA per step off the critical path.
+// (The previous version kept a row per lane and broadcast with 2 x 135 v_readlane: 5.0 us per
+// sub-block, measured with tools/potf2_probe; the chain here is readlane -> rsqrt -> mul -> mfma.)
+// Writes L (lower) back to S and W to Wd[r*WD_LD + c] (zero above the diagonal).
 __device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int b,
                                                      double* __restrict__ Wd,
                                                      int32_t* __restrict__ info, int32_t col0,
                                                      int lane) {
-    const int r = lane & 15;
-    double a[SB], rdk[SB];  // rdk[k] = 1 / L_kk (wave uniform), reused by the inversion
+    const int lo = lane & 15, hi = lane >> 4;
+    double4_t A, W;
 #pragma unroll
-    for (int c = 0; c < SB; ++c) a[c] = S[(b + c) * LDS_LD + b + r];
+    for (int v = 0; v < 4; ++v) {
+        const int row = hi + 4 * v;
+        A[v] = (row >= lo) ? S[(b + lo) * LDS_LD + b + row] : S[(b + row) * LDS_LD + b + lo];
+        W[v] = (row == lo) ? 1.0 : 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
-        double akk = readlane_f64(a[k], k);
+        const int g = k & 3, v = k >> 2;
+        const double arow = A[v];  // row k of the block in the lanes of group g
+        double akk = readlane_f64(arow, 16 * g + k);
         if (!(akk > 0.0)) {  // not positive definite (or NaN): record the first column, go on
             if (lane == 0) atomicCAS(info, 0, col0 + b + k + 1);
             akk = 1.0;
         }
-        // this 16-step chain is the critical path of the whole factorisation: one rsqrt instead of
-        // sqrt + divide, fused multiply-adds for the rank-1 update
-        const double rd = rsqrt(akk);
-        const double d = akk * rd;
-        rdk[k] = rd;
-        const double lk = (r == k) ? d : a[k] * rd;
-        a[k] = lk;
-#pragma unroll
-        for (int c = k + 1; c < SB; ++c) {
-            const double lck = readlane_f64(lk, c);
-            a[c] = __builtin_fma(-lk, lck, a[c]);
-        }
+        // straight-line selects only: every instruction here is on the critical chain of the block
+        const double rd = fast_rsqrt(akk);
+        const double d = akk * rd;  // l_kk
+        const double t = arow * rd;
+        const bool ing = (hi == g), gt = ing && (lo > k), eq = ing && (lo == k);
+        double lk = gt ? t : 0.0;  // l_k over the lanes of group g; exact zeros above the diagonal
+        lk = eq ? d : lk;
+        if (ing && lo >= k) S[(b + k) * LDS_LD + b + lo] = lk;
+        A = __builtin_amdgcn_mfma_f64_16x16x4f64(-lk, lk, A, 0, 0, 0);
+        // W <- E_k W: row k scaled by 1/l_kk in place, then W[i,:] -= l_ik W[k,:] for i > k.  (Folding
+        // the scaling into the product, a = l_k - e_k, cancels catastrophically for large pivots.)
+        const double wk = ing ? W[v] * rd : 0.0;
+        W[v] = ing ? wk : W[v];
+        const double aw = gt ? t : 0.0;
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(-aw, wk, W, 0, 0, 0);
     }
-    if (lane < SB) {
 #pragma unroll
-        for (int c = 0; c < SB; ++c)
-            if (r >= c) S[(b + c) * LDS_LD + b + r] = a[c];
-    }
-    // inverse: lane cc computes column cc of W by forward substitution over the rows
-    const int cc = r;
-    double w[SB];
-#pragma unroll
-    for (int rr = 0; rr < SB; ++rr) {
-        const double inv = rdk[rr];
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < rr; ++k) acc = __builtin_fma(readlane_f64(a[k], rr), w[k], acc);
-        w[rr] = (rr == cc) ? inv : ((rr > cc) ? -(acc * inv) : 0.0);
-    }
-    if (lane < SB) {
-#pragma unroll
-        for (int rr = 0; rr < SB; ++rr) Wd[rr * WD_LD + cc] = w[rr];
-    }
+    for (int v = 0; v < 4; ++v) Wd[(hi + 4 * v) * WD_LD + lo] = W[v];
 }
 
 // Cholesky of one nb x nb (nb <= 128) diagonal block, resident in LDS, and the inverse of its
@@ -108,6 +120,15 @@ __device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int
 // is then completed with a unit pivot so that the launch always terminates.
 // Outputs: L_jj in place; Wcm[r + c*NB] = W(r,c) (column-major) and Wrm[c + r*NB] = W(r,c)
 // (row-major), both zero padded to 128 x 128.
+#ifdef MADQP_POTF2_STAMPS
+__device__ unsigned long long madqp_potf2_stamps[64];  // diagnostic build only (tools/potf2_probe.cpp)
+#define P2_STAMP(i)                                                                    \
+    do {                                                                               \
+        if (threadIdx.x == 0) madqp_potf2_stamps[i] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define P2_STAMP(i)
+#endif
 struct Potf2Batch {  // problem blockIdx.x: pointer strides (doubles / ints); skip[b] != 0: leave untouched
     int64_t sA, sW, sInfo;
     const int32_t* skip;
@@ -129,22 +150,50 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
     __shared__ double Wd[NSB * SB * WD_LD];     // inverse diagonal sub-blocks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 15, hi = lane >> 4;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int c = idx / NB, r = idx % NB;
-        double v = 0.0;
-        if (r < nb && c < nb) {
-            if (r >= c) v = A[r + (int64_t)c * lda];
-        } else if (r == c) {
-            v = 1.0;  // identity padding keeps the padded block positive definite
+    P2_STAMP(0);
+    {  // lower triangle -> LDS: row r = tid & 127, columns (tid >> 7) + 2i; 16 loads in flight per thread
+        const int r = tid & (NB - 1), c0 = tid >> 7;
+#pragma unroll
+        for (int i0 = 0; i0 < NB / 2; i0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = c0 + 2 * (i0 + i);
+                double x = 0.0;
+                if (r < nb && c < nb) {
+                    if (r >= c) x = A[r + (int64_t)c * lda];
+                } else if (r == c) {
+                    x = 1.0;  // identity padding keeps the padded block positive definite
+                }
+                v[i] = x;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[(c0 + 2 * (i0 + i)) * LDS_LD + r] = v[i];
         }
-        S[c * LDS_LD + r] = v;
     }
     __syncthreads();
+    P2_STAMP(1);
+    // one 16 x 16 trailing tile (K, I) of step J: A_IK -= L_IJ L_KJ'
+    auto trailing_tile = [&](int J, int K, int I) {
+        const int b = J * SB;
+        double4_t acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = S[(SB * K + lo) * LDS_LD + SB * I + hi + 4 * v];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double av = -S[(b + 4 * s + hi) * LDS_LD + SB * I + lo];  // -L_IJ[lo][k]
+            const double bv = S[(b + 4 * s + hi) * LDS_LD + SB * K + lo];   //  L_KJ[lo][k]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) S[(SB * K + lo) * LDS_LD + SB * I + hi + 4 * v] = acc[v];
+    };
+    if (wave == 0) diag16_factor_invert(S, 0, Wd, info, col0, lane);
+    __syncthreads();
+    P2_STAMP(2);
     for (int J = 0; J < NSB; ++J) {
         const int b = J * SB;
         double* WdJ = Wd + J * SB * WD_LD;
-        if (wave == 0) diag16_factor_invert(S, b, WdJ, info, col0, lane);
-        __syncthreads();
         // panel: L_IJ = A_IJ * W_JJ'
         for (int I = J + 1 + wave; I < NSB; I += 4) {
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -158,31 +207,38 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
             for (int v = 0; v < 4; ++v) S[(b + lo) * LDS_LD + SB * I + hi + 4 * v] = acc[v];
         }
         __syncthreads();
-        // trailing update: A_IK -= L_IJ * L_KJ'   (J < K <= I)
-        int t = 0;
-        for (int K = J + 1; K < NSB; ++K) {
-            for (int I = K; I < NSB; ++I, ++t) {
-                if ((t & 3) != wave) continue;
-                double4_t acc;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[v] = S[(SB * K + lo) * LDS_LD + SB * I + hi + 4 * v];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const double av = -S[(b + 4 * s + hi) * LDS_LD + SB * I + lo];  // -L_IJ[lo][k]
-                    const double bv = S[(b + 4 * s + hi) * LDS_LD + SB * K + lo];   //  L_KJ[lo][k]
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int v = 0; v < 4; ++v) S[(SB * K + lo) * LDS_LD + SB * I + hi + 4 * v] = acc[v];
+        P2_STAMP(3 + 3 * J);
+        // trailing update with look-ahead: wave 0 updates the next diagonal tile and factors it at once
+        // (the 16-step chain of diag16_factor_invert is the critical path) while waves 1..3 update the
+        // other tiles of this step
+        if (J + 1 < NSB) {
+            if (wave == 0) {
+                trailing_tile(J, J + 1, J + 1);
+                diag16_factor_invert(S, b + SB, WdJ + SB * WD_LD, info, col0, lane);
+            } else {
+                int t = 0;
+                for (int K = J + 1; K < NSB; ++K)
+                    for (int I = K; I < NSB; ++I) {
+                        if (K == J + 1 && I == J + 1) continue;
+                        if ((t++ % 3) + 1 == wave) trailing_tile(J, K, I);
+                    }
             }
         }
         __syncthreads();
+        P2_STAMP(4 + 3 * J);
     }
-    // factor -> global (lower triangle only)
-    for (int idx = tid; idx < nb * nb; idx += 256) {
-        const int c = idx / nb, r = idx % nb;
-        if (r >= c) A[r + (int64_t)c * lda] = S[c * LDS_LD + r];
+    // factor -> global (lower triangle only): row r = tid & 127, columns (tid >> 7) + 2i
+    {
+        const int r = tid & (NB - 1), c0 = tid >> 7;
+        if (r < nb) {
+#pragma unroll 8
+            for (int i = 0; i < NB / 2; ++i) {
+                const int c = c0 + 2 * i;
+                if (c <= r) A[r + (int64_t)c * lda] = S[c * LDS_LD + r];
+            }
+        }
     }
+    P2_STAMP(26);
     // W = L^-1: block columns {0}, {1,6}, {2,5,7}, {3,4} on waves 0..3 (balanced MFMA counts)
     for (int q = 0; q < 3; ++q) {
         int J;
@@ -216,22 +272,23 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        {  // column-major image: idx = c*NB + r
-            const int c = idx / NB, r = idx % NB;
-            double v = 0.0;
-            if (r < nb && c < nb && r >= c)
-                v = (r / SB == c / SB) ? Wd[((r / SB) * SB + r % SB) * WD_LD + c % SB] : S[r * LDS_LD + c];
-            Wcm[idx] = v;
-        }
-        {  // row-major image: idx = r*NB + c
-            const int r = idx / NB, c = idx % NB;
-            double v = 0.0;
-            if (r < nb && c < nb && r >= c)
-                v = (r / SB == c / SB) ? Wd[((r / SB) * SB + r % SB) * WD_LD + c % SB] : S[r * LDS_LD + c];
-            Wrm[idx] = v;
+    P2_STAMP(27);
+    // only the lower triangles are written: the images are zero filled once when they are allocated
+    {
+        const int i = tid & (NB - 1), j0 = tid >> 7;
+        auto W_at = [&](int r, int c) {
+            return (r / SB == c / SB) ? Wd[r * WD_LD + c % SB] : S[r * LDS_LD + c];
+        };
+        if (i < nb) {
+#pragma unroll 8
+            for (int q = 0; q < NB / 2; ++q) {
+                const int j = j0 + 2 * q;
+                if (j <= i) Wcm[j * NB + i] = W_at(i, j);            // column-major: r = i (fast), c = j
+                if (j >= i && j < nb) Wrm[j * NB + i] = W_at(j, i);  // row-major:    c = i (fast), r = j
+            }
         }
     }
+    P2_STAMP(28);
 }
 
 // ---- triangular sweeps, one launch each ---------------------------------------------------------
@@ -491,6 +548,7 @@ extern "C" int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out
     s->d_info = nullptr;
     const int64_t nblk = std::max<int64_t>(1, (n + NB - 1) / NB);
     hipError_t e = hipMalloc(&s->winv, nblk * WBLK * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(s->winv, 0, nblk * WBLK * sizeof(double));  // the kernel writes lower parts only
     if (e == hipSuccess) e = hipMalloc(&s->tmp, std::max<int64_t>(NB, n) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&s->d_info, 8 * sizeof(int32_t));  // [0] info, [1..3] sweep tickets / error
     if (e != hipSuccess) {
