@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from ._lib import BATCH_SCALARS, CBatchData, ptr
-from .options import AdaptiveStep, ConservativeStep, IPMOptions
+from .options import IPMOptions
 from .solver import _push_interior, get_index_constraints, native_options
 
 
@@ -27,10 +27,8 @@ class BatchedMPCSolver:
             raise ValueError("empty batch")
         self.be, self.qps = backend, list(qps)
         self.opt = IPMOptions(**opts)
-        if self.opt.kkt_system != "condensed" or self.opt.max_ncorr != 0 or self.opt.distributed:
-            raise ValueError("the batched driver supports the condensed KKT system with max_ncorr = 0")
-        if not isinstance(self.opt.step_rule, (AdaptiveStep, ConservativeStep)):
-            raise ValueError("the batched driver supports ConservativeStep and AdaptiveStep")
+        if self.opt.kkt_system != "condensed" or self.opt.distributed or self.opt.check_residual:
+            raise ValueError("the batched driver supports the condensed KKT system on one GPU")
         q0 = self.qps[0]
         self.B, self.nx, self.m = len(self.qps), q0.nvar, q0.ncon
         dev = backend.device

@@ -14,8 +14,8 @@
 //   * the host only reads the status words (one small copy per call of madqp_batch_iterate).
 //
 // Same arithmetic as the single-problem path (src/solver.jl:127-182, 254-345 in the same order);
-// sums are accumulated in a different order, so results agree to rounding, not bitwise.  Not covered
-// here (use the per-problem driver): Gondzio corrections, MehrotraAdaptiveStep, the x100
+// sums are accumulated in a different order, so results agree to rounding, not bitwise.  All step
+// rules and Gondzio's corrections are in; not covered here (use the per-problem driver): the x100
 // regularization retry (a failed factorisation ends that problem with status -3), normal equations.
 #include <algorithm>
 #include <cmath>
@@ -54,7 +54,7 @@ struct BQ {  // device view of the batch (by value in the kernel arguments); pro
     const int64_t *ind_lb, *ind_ub, *ind_ineq, *slot;
     const double *H, *A, *q, *rhs, *c0;
     double *x, *xl, *xu, *zl, *zu, *y;
-    double *f, *c, *jacl, *reg, *pr_diag, *du_diag, *d, *p, *w1;
+    double *f, *c, *jacl, *reg, *pr_diag, *du_diag, *d, *p, *w1, *w2;
     double *l_diag, *l_lower, *u_diag, *u_lower, *corr_lb, *corr_ub;
     double *theta, *t, *u, *K, *S, *winv, *tmp;
     double* scal;
@@ -308,22 +308,6 @@ __device__ double wg_eval_model(const BQ& q, const madqp_state& s, const Prob& p
     return obj;
 }
 
-// (alpha_p, alpha_d) of get_fraction_to_boundary_step (src/kernels.jl:290-305)
-__device__ void wg_fraction_to_boundary(const madqp_state& s, double tau, double* red, double& ap, double& ad) {
-    if (s.nlb + s.nub == 0) {
-        ap = ad = 1.0;
-        return;
-    }
-    wg::alpha_max_kernel(s, tau, red);
-    WG_SYNC();
-    double a[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) a[k] = (red[2 * k] < 1.0) ? red[2 * k] : 1.0;  // init = (1.0, 0)
-    WG_SYNC();
-    ap = fmin(a[0], a[1]);
-    ad = fmin(a[2], a[3]);
-}
-
 __device__ double wg_compl(const madqp_state& s, int affine, double ap, double ad, double* red) {
     if (s.nlb + s.nub == 0) return 0.0;
     wg::compl_kernel(s, affine, ap, ad, red);
@@ -331,6 +315,73 @@ __device__ double wg_compl(const madqp_state& s, int affine, double ap, double a
     const double v = (red[0] + red[1]) / (double)(s.nlb + s.nub);
     WG_SYNC();
     return v;
+}
+
+// the four (value, blocking index) pairs of get_alpha_max_primal / _dual (src/kernels.jl:242-288)
+__device__ void wg_alpha_max(const madqp_state& s, double tau, double* red, double (&a)[4], int64_t (&ib)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = 1.0;
+        ib[k] = -1;
+    }
+    if (s.nlb + s.nub == 0) return;
+    wg::alpha_max_kernel(s, tau, red);
+    WG_SYNC();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (red[2 * k] < 1.0) {  // init = (1.0, 0): alpha <= 1, "nothing blocks" otherwise
+            a[k] = red[2 * k];
+            ib[k] = (int64_t)red[2 * k + 1];
+        }
+    WG_SYNC();
+}
+// (alpha_p, alpha_d) of get_fraction_to_boundary_step (src/kernels.jl:290-305)
+__device__ void wg_fraction_to_boundary(const madqp_state& s, double tau, double* red, double& ap, double& ad) {
+    double a[4];
+    int64_t ib[4];
+    wg_alpha_max(s, tau, red, a, ib);
+    ap = fmin(a[0], a[1]);
+    ad = fmin(a[2], a[3]);
+}
+
+// update_step!(::MehrotraAdaptiveStep) (src/kernels.jl:325-374): element reads at the blocking indices
+__device__ void wg_mehrotra_adaptive_step(const madqp_state& s, double gamma_f, double* red, double& alpha_p,
+                                          double& alpha_d) {
+    const double gamma_a = 1.0 / (1.0 - gamma_f);
+    double a[4];
+    int64_t ib[4];
+    wg_alpha_max(s, 1.0, red, a, ib);
+    const double max_ap = fmin(a[0], a[1]), max_ad = fmin(a[2], a[3]);
+    const double mu_full = wg_compl(s, 1, max_ap, max_ad, red) / gamma_a;
+    const double* dx = s.d;
+    const double* dzl = s.d + s.n + s.m;
+    const double* dzu = dzl + s.nlb;
+    alpha_p = 1.0;
+    alpha_d = 1.0;
+    if (max_ap < 1.0) {
+        if (a[0] <= a[1]) {
+            const int64_t i = ib[0], j = s.ind_lb[i];
+            const double tmp = mu_full / (s.zl[j] + max_ad * dzl[i]);
+            alpha_p = (s.x[j] - s.xl[j] - tmp) / (-dx[j]);
+        } else {
+            const int64_t i = ib[1], j = s.ind_ub[i];
+            const double tmp = mu_full / (s.zu[j] + max_ad * dzu[i]);
+            alpha_p = (s.xu[j] - s.x[j] - tmp) / dx[j];
+        }
+    }
+    if (max_ad < 1.0) {
+        if (a[2] <= a[3]) {
+            const int64_t i = ib[2], j = s.ind_lb[i];
+            const double tmp = mu_full / (s.x[j] + max_ap * dx[j] - s.xl[j]);
+            alpha_d = -(s.zl[j] - tmp) / dzl[i];
+        } else {
+            const int64_t i = ib[3], j = s.ind_ub[i];
+            const double tmp = mu_full / (s.xu[j] - s.x[j] - max_ap * dx[j]);
+            alpha_d = -(s.zu[j] - tmp) / dzu[i];
+        }
+    }
+    alpha_p = fmax(alpha_p, gamma_f * max_ap);
+    alpha_d = fmax(alpha_d, gamma_f * max_ad);
 }
 
 // Theta and the scaled operand S = sqrt(Theta) A (zero padded to kpad x npad) of build_kkt!
@@ -566,11 +617,45 @@ __global__ __launch_bounds__(TPB) void bq_iter_post_kernel(BQ q) {
         wg::rhs_kernel(s, 1, mu);  // set_correction_rhs! :307
         WG_SYNC();
         if (!wg_solve_system(q, s, pb, lds, red)) status = ST_STEP_ERROR;
+        // gondzio_correction_direction! (src/solver.jl:200-251)
+        if (status == ST_ACTIVE && q.opt.max_ncorr > 0) {
+            const double delta = 0.1, bmin = 0.1, bmax = 10.0, tau_g = 0.995;
+            double* w2 = q.w2 + b * q.ntot;
+            double ap, ad;
+            wg_fraction_to_boundary(s, tau_g, red, ap, ad);
+            for (int c = 0; c < q.opt.max_ncorr; ++c) {
+                const double ta_p = fmin(ap + delta, 1.0), ta_d = fmin(ad + delta, 1.0);
+                const double ga = wg_compl(s, 1, ta_p, ta_d, red);
+                const double mu_g = (ga / mu_curr) * (ga / mu_curr) * ga;
+                wg::extra_correction_kernel(s, ta_p, ta_d, bmin * mu_g, bmax * mu_g);
+                WG_SYNC();
+                wg::rhs_kernel(s, 1, mu_g);
+                wg_copy(q.ntot, s.d, w2);
+                WG_SYNC();
+                if (!wg_solve_system(q, s, pb, lds, red)) {
+                    status = ST_STEP_ERROR;
+                    break;
+                }
+                double ha_p, ha_d;
+                wg_fraction_to_boundary(s, tau_g, red, ha_p, ha_d);
+                if (ha_p < 1.005 * ap || ha_d < 1.005 * ad) {
+                    wg_copy(q.ntot, w2, s.d);
+                    WG_SYNC();
+                    break;
+                }
+                ap = ha_p;
+                ad = ha_d;
+            }
+        }
     }
     if (status == ST_ACTIVE) {
-        // update_step! (src/kernels.jl:307-323)
-        const double tau = (q.opt.step_rule == 0) ? q.opt.step_param : fmax(1.0 - mu, q.opt.step_param);
-        wg_fraction_to_boundary(s, tau, red, alpha_p, alpha_d);
+        // update_step! (src/kernels.jl:307-374)
+        if (q.opt.step_rule == 2) {
+            wg_mehrotra_adaptive_step(s, q.opt.step_param, red, alpha_p, alpha_d);
+        } else {
+            const double tau = (q.opt.step_rule == 0) ? q.opt.step_param : fmax(1.0 - mu, q.opt.step_param);
+            wg_fraction_to_boundary(s, tau, red, alpha_p, alpha_d);
+        }
         wg::norm_inf3_kernel(s.n, s.d, nullptr, nullptr, red);  // print_iter, src/structure.jl:190
         WG_SYNC();
         dnorm = red[0];
@@ -681,7 +766,7 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
     ARG_TRY(ctx, nlb >= 0 && nub >= 0 && (nlb == 0 || ind_lb) && (nub == 0 || ind_ub) && (ns == 0 || ind_ineq_host));
     ARG_TRY(ctx, (nx == 0 || (data->q && data->x && data->xl && data->xu && data->zl && data->zu)) &&
                      (m == 0 || (data->A && data->rhs && data->y)) && data->c0);
-    ARG_TRY(ctx, opt->step_rule >= 0 && opt->step_rule <= 1 && opt->max_ncorr == 0 && opt->regularization >= 0 &&
+    ARG_TRY(ctx, opt->step_rule >= 0 && opt->step_rule <= 2 && opt->max_ncorr >= 0 && opt->regularization >= 0 &&
                      opt->regularization <= 2);
     // the condensed form needs delta_d < 0 on equality rows (conventions)
     ARG_TRY(ctx, ns == m || (opt->regularization != 0 && opt->delta_d < 0.0));
@@ -741,6 +826,7 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
     BALLOC(q.d, B * q.ntot);
     BALLOC(q.p, B * q.ntot);
     BALLOC(q.w1, B * q.ntot);
+    BALLOC(q.w2, opt->max_ncorr > 0 ? B * q.ntot : 1);
     BALLOC(q.l_diag, B * nlb);
     BALLOC(q.l_lower, B * nlb);
     BALLOC(q.u_diag, B * nub);

@@ -61,6 +61,30 @@ def test_batched_equality_rows_and_step_rule(hip):
         M.BatchedMPCSolver([to_device(q, hip) for q in qps], hip)
 
 
+@pytest.mark.parametrize("variant", ["gondzio", "mehrotra_step", "adaptive_reg"])
+def test_batched_options(hip, variant):
+    """Gondzio corrections (per-problem number of accepted corrections), MehrotraAdaptiveStep (element
+    reads at the blocking indices) and AdaptiveRegularization inside the lock-step engine."""
+    qps = [Q.synthetic_qp(1200 + i, 72, 30) for i in range(7)]
+    dq = [to_device(q, hip) for q in qps]
+    kw, okw = dict(regularization=REG), dict(regularization=OREG)
+    if variant == "gondzio":
+        kw["max_ncorr"], okw["max_ncorr"] = 3, 3
+    elif variant == "mehrotra_step":
+        kw["step_rule"], okw["step_rule"] = M.MehrotraAdaptiveStep(0.99), mpc.MehrotraAdaptiveStep(0.99)
+    else:
+        kw["regularization"] = M.AdaptiveRegularization(1e-8, -1e-9, 1e-9)
+        okw["regularization"] = mpc.AdaptiveRegularization(1e-8, -1e-9, 1e-9)
+    s = M.BatchedMPCSolver(dq, hip, **kw)
+    res = s.solve()
+    s.close()
+    for i, (qp, r) in enumerate(zip(qps, res)):
+        ref = mpc.solve(qp, kkt_system="condensed", **okw)
+        assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"], (i, r["iter"], ref["iter"])
+        assert close(r["objective"], ref["objective"], 1e-9)
+        assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+
+
 def test_batched_is_the_per_problem_driver(hip):
     """Same library, two drivers: the batch and MPCSolver agree problem by problem; a problem that
     breaks down (indefinite H) ends with an error status and leaves the others untouched; a permuted
@@ -95,4 +119,4 @@ def test_batched_rejects_mixed_patterns(hip):
     with pytest.raises(ValueError):
         M.BatchedMPCSolver([to_device(a, hip), to_device(b, hip)], hip, regularization=REG)
     with pytest.raises(ValueError):
-        M.BatchedMPCSolver([to_device(a, hip)], hip, regularization=REG, max_ncorr=2)
+        M.BatchedMPCSolver([to_device(a, hip)], hip, regularization=REG, kkt_system="normal")
