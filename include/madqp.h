@@ -240,6 +240,18 @@ int32_t madqp_kkt_eval(madqp_kkt* kkt, const madqp_state* st, const double* q, c
 /* device pointer to the assembled / factored K (nx x nx, ld = madqp_kkt_ld) for inspection */
 int32_t madqp_kkt_matrix(madqp_kkt* kkt, double** K, int64_t* ld);
 
+/* ----------------------------------------- sparse-A front end */
+/* create_kkt_system with the Jacobian kept sparse, as the reference does (coo_to_csr src/utils.jl:148-197,
+ * src/KKT/normalkkt.jl:51-101): A in CSR (a_*: m rows) and A' in CSR (at_*: nx rows = the CSC of A), device
+ * int64 / double arrays, column indices ascending within a row, borrowed.  mode 0: condensed
+ * K = H + Sigma_x + A' Theta A (H dense or NULL); mode 1: normal equations A Sigma^-1 A' (LP only,
+ * assemble_normal_system! src/utils.jl:266-298).  The factorised matrix stays dense; every madqp_kkt_*
+ * call works on the returned object (products with A / A' become CSR mat-vecs). */
+int32_t madqp_kkt_create_sparse(madqp_ctx* ctx, int32_t mode, int64_t nx, int64_t m, int64_t ns,
+                                const int64_t* ind_ineq_host, const double* H, int64_t ldh, const int64_t* a_ptr,
+                                const int64_t* a_col, const double* a_val, const int64_t* at_ptr,
+                                const int64_t* at_col, const double* at_val, madqp_kkt** out);
+
 /* ----------------------------------------- multi-GPU factorisation pieces */
 /* One dense KKT over several GPUs, one process per GPU: block columns ("panels", starts and widths
  * multiples of 128, the last one may be short) are dealt round-robin to the ranks.  A rank assembles

@@ -10,15 +10,17 @@ from ._lib import EXPORTED_SYMBOLS, LIB_PATH, MadQPError, load_cdll
 from .backend import HipBackend, State
 from .batch import shard, solve_batch
 from .batched import BatchedMPCSolver
-from .kkt import HIPCholeskySolver, HIPCondensedKKTSystem, HIPNormalKKTSystem
+from .kkt import (HIPCholeskySolver, HIPCondensedKKTSystem, HIPNormalKKTSystem, HIPSparseCondensedKKTSystem,
+                  HIPSparseNormalKKTSystem)
 from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, FixedRegularization,
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
-from .qp import DeviceQP, stream_key
+from .qp import DeviceCSR, DeviceQP, stream_key
 from .solver import (ERROR_IN_STEP_COMPUTATION, MAXIMUM_ITERATIONS_EXCEEDED, SOLVE_SUCCEEDED,
                      MPCSolver, SolveException)
 
 __all__ = [
-    "HipBackend", "State", "shard", "solve_batch", "BatchedMPCSolver", "HIPCholeskySolver", "HIPCondensedKKTSystem", "HIPNormalKKTSystem", "MPCSolver", "DeviceQP",
+    "HipBackend", "State", "shard", "solve_batch", "BatchedMPCSolver", "HIPCholeskySolver", "HIPCondensedKKTSystem", "HIPNormalKKTSystem", "HIPSparseCondensedKKTSystem", "HIPSparseNormalKKTSystem", "MPCSolver", "DeviceQP",
+    "DeviceCSR",
     "IPMOptions", "AdaptiveStep", "ConservativeStep", "MehrotraAdaptiveStep", "NoRegularization",
     "FixedRegularization", "AdaptiveRegularization", "MadQPError", "SolveException", "load_cdll",
     "EXPORTED_SYMBOLS", "LIB_PATH", "stream_key", "SOLVE_SUCCEEDED", "MAXIMUM_ITERATIONS_EXCEEDED",

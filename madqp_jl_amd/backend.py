@@ -283,6 +283,15 @@ class HipBackend:
         self._ck(self.lib.madqp_kkt_create_normal(self.ctx, nx, m, ns, arr, ptr(At), ldat, C.byref(h)))
         return h
 
+    def kkt_create_sparse(self, mode, nx, m, ind_ineq, H, ldh, csr, t_val):
+        """``csr``: :class:`DeviceCSR`; ``t_val``: values of A' in its CSR order (kept alive by the caller)."""
+        h = C.c_void_p()
+        ineq = (C.c_int64 * max(1, len(ind_ineq)))(*[int(i) for i in ind_ineq])
+        self._ck(self.lib.madqp_kkt_create_sparse(self.ctx, mode, nx, m, len(ind_ineq), ineq, ptr(H), ldh,
+                                                  ptr(csr.ptr), ptr(csr.col), ptr(csr.val), ptr(csr.t_ptr),
+                                                  ptr(csr.t_col), ptr(t_val), C.byref(h)))
+        return h
+
     def kkt_destroy(self, h):
         self.lib.madqp_kkt_destroy(h)
 

@@ -32,6 +32,9 @@ struct madqp_kkt {
     int64_t lda;
     const double* At;  // nx x m, row k = variable k contiguous (normal mode)
     int64_t ldat;
+    // sparse front end (either mode): CSR of A (m rows) and CSR of A' (nx rows); A == At == nullptr then
+    const int64_t *a_ptr, *a_col, *at_ptr, *at_col;
+    const double *a_val, *at_val;
     double *dn, *tn;  // normal mode: 1/Sigma (n) and an n-vector of scratch
     int64_t* d_ind_ineq;  // ns
     int64_t* d_slot;      // m: slack slot of a row, -1 for an equality row
@@ -61,10 +64,14 @@ inline int grid_for(int64_t len) {
 
 // y(m) = alpha A x(nx) + beta y   /   y(nx) = alpha A' x(m) + beta y, from whichever layout is held
 static int32_t apply_A(madqp_kkt* k, double alpha, const double* x, double beta, double* y) {
+    if (k->a_ptr)
+        return madqp_spmv_csr(k->ctx, k->m, k->a_ptr, k->a_col, k->a_val, alpha, x, beta, y, MADQP_PROF_GEMV);
     if (k->A) return madqp_gemv_impl(k->ctx, 0, k->m, k->nx, alpha, k->A, k->lda, x, beta, y, MADQP_PROF_GEMV);
     return madqp_gemv_impl(k->ctx, 1, k->nx, k->m, alpha, k->At, k->ldat, x, beta, y, MADQP_PROF_GEMV);
 }
 static int32_t apply_At(madqp_kkt* k, double alpha, const double* x, double beta, double* y) {
+    if (k->a_ptr)
+        return madqp_spmv_csr(k->ctx, k->nx, k->at_ptr, k->at_col, k->at_val, alpha, x, beta, y, MADQP_PROF_GEMV);
     if (k->A) return madqp_gemv_impl(k->ctx, 1, k->m, k->nx, alpha, k->A, k->lda, x, beta, y, MADQP_PROF_GEMV);
     return madqp_gemv_impl(k->ctx, 0, k->nx, k->m, alpha, k->At, k->ldat, x, beta, y, MADQP_PROF_GEMV);
 }
@@ -158,6 +165,29 @@ extern "C" int32_t madqp_kkt_create(madqp_ctx* ctx, int64_t nx, int64_t m, int64
     return kkt_create_common(ctx, KKT_CONDENSED, nx, m, ns, ind_ineq_host, H, ldh, A, lda, nullptr, 0, out);
 }
 
+// Sparse front end: A as CSR (a_*: m rows, column indices < nx, ascending within a row) and A' as CSR
+// (at_*: nx rows, indices < m), both device, int64, borrowed.  mode 0: condensed K = H + Sigma_x + A' Theta A
+// (H dense or NULL), mode 1: the reference's normal equations A Sigma^-1 A' (LP only).
+extern "C" int32_t madqp_kkt_create_sparse(madqp_ctx* ctx, int32_t mode, int64_t nx, int64_t m, int64_t ns,
+                                           const int64_t* ind_ineq_host, const double* H, int64_t ldh,
+                                           const int64_t* a_ptr, const int64_t* a_col, const double* a_val,
+                                           const int64_t* at_ptr, const int64_t* at_col, const double* at_val,
+                                           madqp_kkt** out) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, (mode == 0 || mode == 1) && a_ptr && at_ptr && (!H || ldh >= nx) && !(mode == 1 && H));
+    int32_t r = kkt_create_common(ctx, mode == 1 ? KKT_NORMAL : KKT_CONDENSED, nx, m, ns, ind_ineq_host, H, ldh,
+                                  nullptr, 0, nullptr, 0, out);
+    if (r) return r;
+    madqp_kkt* k = *out;
+    k->a_ptr = a_ptr;
+    k->a_col = a_col;
+    k->a_val = a_val;
+    k->at_ptr = at_ptr;
+    k->at_col = at_col;
+    k->at_val = at_val;
+    return MADQP_OK;
+}
+
 extern "C" int32_t madqp_kkt_create_normal(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
                                            const int64_t* ind_ineq_host, const double* At,
                                            int64_t ldat, madqp_kkt** out) {
@@ -191,12 +221,22 @@ static int32_t kkt_build_impl(madqp_kkt* k, const madqp_state* st, int64_t nrang
             if (st->n) KLAUNCH(recip_kernel, st->n, st->n, st->pr_diag, k->dn);
             if (k->m) KLAUNCH(slack_diag_kernel, k->m, k->m, k->nx, k->d_slot, k->dn, k->theta);
         }
+        if (k->a_ptr) {  // V = A (rows = constraints), weights 1/Sigma over the variables
+            ARG_TRY(ctx, ranges == nullptr);
+            return madqp_sparse_gram(ctx, k->m, k->a_ptr, k->a_col, k->a_val, k->dn, nullptr, 0, k->theta, k->K,
+                                     k->ldk);
+        }
         return madqp_syrk_assemble_ranges(ctx, k->m, k->nx, k->At, k->ldat, k->dn, nullptr, 0, k->theta,
                                           k->K, k->ldk, nranges, ranges);
     }
     if (k->m) {
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(theta_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, k->theta);
+    }
+    if (k->a_ptr) {  // V = A' (rows = variables), weights Theta over the constraints
+        ARG_TRY(ctx, ranges == nullptr);
+        return madqp_sparse_gram(ctx, k->nx, k->at_ptr, k->at_col, k->at_val, k->theta, k->H, k->ldh, st->pr_diag,
+                                 k->K, k->ldk);
     }
     return madqp_syrk_assemble_ranges(ctx, k->nx, k->m, k->A, k->lda, k->theta, k->H, k->ldh, st->pr_diag,
                                       k->K, k->ldk, nranges, ranges);

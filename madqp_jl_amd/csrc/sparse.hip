@@ -1,0 +1,88 @@
+// Sparse-A front end: the Jacobian arrives in CSR (the reference keeps it sparse:
+// coo_to_csr, src/utils.jl:148-197; NormalKKTSystem constructor, src/KKT/normalkkt.jl:51-101) but the
+// matrix that is factorised stays the DENSE condensed / normal matrix of this library, so the MFMA
+// Cholesky and the triangular sweeps are unchanged.  Two pieces:
+//   * y = alpha M x + beta y for a CSR matrix (products with A use the CSR of A, products with A' the
+//     CSR of A' = the CSC of A, built once by the host: no atomics, fixed summation order);
+//   * the weighted Gram matrix  C = base + diag(dvec) + V diag(w) V'  (lower triangle, dense, column
+//     major) of the sparse rows of V -- assemble_normal_system! (src/utils.jl:266-298) with V = A,
+//     w = 1/Sigma for the normal equations, and V = A', w = Theta for the condensed form.  One thread
+//     per entry (i, j), a merge of the two sorted index lists: deterministic, no atomics.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+__global__ __launch_bounds__(256) void spmv_csr_kernel(int64_t rows, const int64_t* __restrict__ rowptr,
+                                                       const int64_t* __restrict__ col,
+                                                       const double* __restrict__ val, double alpha,
+                                                       const double* __restrict__ x, double beta,
+                                                       double* __restrict__ y) {
+    // a quarter wave (16 lanes) per row: short rows dominate in LP / QP Jacobians
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    double acc = 0.0;
+    if (r < rows) {
+        const int64_t e = rowptr[r + 1];
+        for (int64_t p = rowptr[r] + sub; p < e; p += 16) acc += val[p] * x[col[p]];
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_down(acc, off, 16);
+    if (r < rows && sub == 0) y[r] = (beta == 0.0) ? alpha * acc : alpha * acc + beta * y[r];
+}
+
+__global__ __launch_bounds__(256) void sparse_gram_kernel(int64_t n, const int64_t* __restrict__ rowptr,
+                                                          const int64_t* __restrict__ col,
+                                                          const double* __restrict__ val,
+                                                          const double* __restrict__ w,
+                                                          const double* __restrict__ base, int64_t ldbase,
+                                                          const double* __restrict__ dvec,
+                                                          double* __restrict__ C, int64_t ldc) {
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);  // fast index: rows of column-major C
+    const int64_t j = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= n || j > i) return;
+    int64_t pa = rowptr[i], ea = rowptr[i + 1], pb = rowptr[j], eb = rowptr[j + 1];
+    double acc = 0.0;
+    while (pa < ea && pb < eb) {
+        const int64_t ca = col[pa], cb = col[pb];
+        if (ca == cb) {
+            acc += w[ca] * val[pa] * val[pb];
+            ++pa;
+            ++pb;
+        } else if (ca < cb) {
+            ++pa;
+        } else {
+            ++pb;
+        }
+    }
+    if (base) acc += base[i + j * ldbase];
+    if (dvec && i == j) acc += dvec[i];
+    C[i + j * ldc] = acc;
+}
+}  // namespace
+
+int32_t madqp_spmv_csr(madqp_ctx* ctx, int64_t rows, const int64_t* rowptr, const int64_t* col, const double* val,
+                       double alpha, const double* x, double beta, double* y, int prof_cls) {
+    if (rows == 0) return MADQP_OK;
+    ARG_TRY(ctx, rowptr && x && y);
+    ProfScope ps(ctx, prof_cls);
+    const unsigned grid = (unsigned)((rows * 16 + 255) / 256);
+    hipLaunchKernelGGL(spmv_csr_kernel, dim3(grid), dim3(256), 0, ctx->stream, rows, rowptr, col, val, alpha, x,
+                       beta, y);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
+
+int32_t madqp_sparse_gram(madqp_ctx* ctx, int64_t n, const int64_t* rowptr, const int64_t* col, const double* val,
+                          const double* w, const double* base, int64_t ldbase, const double* dvec, double* C,
+                          int64_t ldc) {
+    if (n == 0) return MADQP_OK;
+    ARG_TRY(ctx, rowptr && w && C && ldc >= n && (!base || ldbase >= n));
+    ProfScope ps(ctx, MADQP_PROF_SYRK);
+    const unsigned t = (unsigned)((n + 15) / 16);
+    ARG_TRY(ctx, t <= 65535);
+    hipLaunchKernelGGL(sparse_gram_kernel, dim3(t, t), dim3(256), 0, ctx->stream, n, rowptr, col, val, w, base,
+                       ldbase, dvec, C, ldc);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}

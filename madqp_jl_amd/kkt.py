@@ -140,3 +140,35 @@ class HIPNormalKKTSystem(HIPCondensedKKTSystem):
 
     def is_inertia_correct(self, num_pos, num_zero, num_neg):  # src/KKT/normalkkt.jl:132-134
         return num_zero == 0 and num_pos == self.m
+
+
+class _SparseMixin:
+    """The Jacobian stays sparse (``DeviceCSR``), the factorised matrix stays dense (SURVEY.md 8f rank 1;
+    reference: src/utils.jl:148-298, src/KKT/normalkkt.jl:51-101)."""
+
+    def _init_sparse(self, backend, st, nx, ind_ineq, H, csr, mode):
+        self.be, self.st = backend, st
+        self.nx, self.m = int(nx), st.m
+        self.ind_ineq = [int(i) for i in ind_ineq]
+        self.ns = len(self.ind_ineq)
+        assert st.n == self.nx + self.ns and (csr.m, csr.n) == (self.m, self.nx)
+        self.H, self.A, self.csr = H, None, csr
+        self._t_val = csr.t_val  # values of A' in CSR order, borrowed by the library
+        self._h = backend.kkt_create_sparse(mode, self.nx, self.m, self.ind_ineq, H, max(self.nx, 1), csr,
+                                            self._t_val)
+        self.linear_solver = HIPCholeskySolver(backend, self._h)
+        self.n_factorizations = 0
+
+
+class HIPSparseCondensedKKTSystem(_SparseMixin, HIPCondensedKKTSystem):
+    def __init__(self, backend, st, nx, ind_ineq, H, csr):
+        if H is not None:
+            assert H.is_contiguous() and H.shape == (nx, nx)
+        self._init_sparse(backend, st, nx, ind_ineq, H, csr, 0)
+
+
+class HIPSparseNormalKKTSystem(_SparseMixin, HIPNormalKKTSystem):
+    def __init__(self, backend, st, nx, ind_ineq, H, csr):
+        if H is not None:
+            raise ValueError("The KKT system NormalKKTSystem supports only linear programs.")  # normalkkt.jl:45-48
+        self._init_sparse(backend, st, nx, ind_ineq, None, csr, 1)

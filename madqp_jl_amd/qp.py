@@ -31,8 +31,59 @@ def stream_key(seed: int, stream: int) -> int:
     return _mix64((seed ^ ((stream * 0xD1B54A32D192ED03) & _MASK)) & _MASK)
 
 
+class DeviceCSR:
+    """A sparse Jacobian on the device: CSR of A (``ptr, col, val``; m rows, column indices ascending within
+    a row) plus what the transposed products need -- the CSR of A' (``t_ptr, t_col``) and the permutation
+    ``t_perm`` with ``val_of_At = val[t_perm]`` -- and ``row`` (row index of every stored entry).  The
+    pattern is built once on the host (A is constant for a QP), the reference's ``coo_to_csr``
+    (src/utils.jl:148-197) in spirit; values can be rescaled on the device without touching it."""
+
+    def __init__(self, device, m, n, rows, cols, vals):
+        rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+        vals = np.asarray(vals, dtype=np.float64)
+        order = np.lexsort((cols, rows))  # by row, then column
+        rows, cols, vals = rows[order], cols[order], vals[order]
+        if len(rows) > 1 and np.any((rows[1:] == rows[:-1]) & (cols[1:] == cols[:-1])):
+            raise ValueError("duplicate entries in the sparse Jacobian")
+        t_perm = np.lexsort((rows, cols))  # by column, then row: the order of the entries of A'
+        dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)
+        count = lambda idx, k: np.concatenate([[0], np.cumsum(np.bincount(idx, minlength=k))])
+        self.m, self.n, self.nnz = int(m), int(n), len(vals)
+        self.ptr, self.col, self.val = dev(count(rows, m), torch.int64), dev(cols, torch.int64), dev(vals, torch.float64)
+        self.row = dev(rows, torch.int64)
+        self.t_ptr, self.t_col = dev(count(cols, n), torch.int64), dev(rows[t_perm], torch.int64)
+        self.t_perm = dev(t_perm, torch.int64)
+
+    @classmethod
+    def from_dense(cls, device, A):
+        A = np.asarray(A, dtype=np.float64)
+        r, c = np.nonzero(A)
+        return cls(device, A.shape[0], A.shape[1], r, c, A[r, c])
+
+    def scaled(self, row_scale):
+        """A copy that shares the pattern, with row i multiplied by ``row_scale[i]``."""
+        out = object.__new__(DeviceCSR)
+        out.__dict__.update(self.__dict__)
+        out.val = (self.val * row_scale[self.row]).contiguous()
+        return out
+
+    @property
+    def t_val(self):
+        return self.val[self.t_perm].contiguous()
+
+    def row_absmax(self):
+        out = torch.zeros(self.m, dtype=torch.float64, device=self.val.device)
+        return out.scatter_reduce(0, self.row, self.val.abs(), reduce="amax", include_self=True)
+
+    def to_dense(self):
+        A = torch.zeros((self.m, self.n), dtype=torch.float64, device=self.val.device)
+        A[self.row, self.col] = self.val
+        return A
+
+
 class DeviceQP:
     def __init__(self, H, q, A, lvar, uvar, lcon, ucon, x0, c0=0.0, y0=None, name="qp"):
+        """``A``: (m, nx) row-major tensor, or a :class:`DeviceCSR` (sparse front end)."""
         self.H, self.q, self.A = H, q, A
         self.lvar, self.uvar, self.lcon, self.ucon, self.x0 = lvar, uvar, lcon, ucon, x0
         self.c0 = float(c0)
@@ -41,12 +92,13 @@ class DeviceQP:
         self.nvar, self.ncon = q.numel(), lcon.numel()
 
     @classmethod
-    def from_numpy(cls, device, H, q, A, lvar, uvar, lcon, ucon, x0, c0=0.0, y0=None, name="qp"):
+    def from_numpy(cls, device, H, q, A, lvar, uvar, lcon, ucon, x0, c0=0.0, y0=None, name="qp", sparse=False):
         f = lambda a: None if a is None else torch.as_tensor(
             np.ascontiguousarray(a, dtype=np.float64), device=device)
         n = len(q)
         Hn = None if (H is None or not np.any(H)) else f(H)
-        An = f(np.asarray(A, dtype=np.float64).reshape(len(lcon), n))
+        A2 = np.asarray(A, dtype=np.float64).reshape(len(lcon), n)
+        An = DeviceCSR.from_dense(device, A2) if sparse else f(A2)
         return cls(Hn, f(q), An, f(lvar), f(uvar), f(lcon), f(ucon), f(x0), c0, f(y0), name)
 
     @classmethod

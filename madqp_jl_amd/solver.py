@@ -18,10 +18,11 @@ import numpy as np
 import torch
 
 from ._lib import CMpcInfo, CMpcOptions
-from .kkt import HIPCondensedKKTSystem, HIPNormalKKTSystem
+from .kkt import (HIPCondensedKKTSystem, HIPNormalKKTSystem, HIPSparseCondensedKKTSystem,
+                  HIPSparseNormalKKTSystem)
 from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, FixedRegularization,
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
-from .qp import DeviceQP
+from .qp import DeviceCSR, DeviceQP
 
 SOLVE_SUCCEEDED = 1
 MAXIMUM_ITERATIONS_EXCEEDED = 6
@@ -303,8 +304,9 @@ class MPCSolver:
         self.H, self.A, self.q = qp.H, qp.A, qp.q
         if opt.scaling and (self.m or nx):  # MadNLP.set_scaling!(..., 100) (:148-159)
             con_scale = torch.ones(self.m, dtype=torch.float64, device=dev)
+            sparse = isinstance(qp.A, DeviceCSR)
             if self.m and nx:
-                rowmax = torch.linalg.vector_norm(qp.A, ord=float("inf"), dim=1)
+                rowmax = qp.A.row_absmax() if sparse else torch.linalg.vector_norm(qp.A, ord=float("inf"), dim=1)
                 con_scale = torch.minimum(one, 100.0 / rowmax)
             g = st.f[:nx]  # scratch: gradient at the pushed start
             g.copy_(qp.q)
@@ -320,7 +322,7 @@ class MPCSolver:
                 st.x[nx:] *= cs
                 st.xl[nx:] *= cs
                 st.xu[nx:] *= cs
-                self.A = (con_scale[:, None] * qp.A).contiguous()
+                self.A = qp.A.scaled(con_scale) if sparse else (con_scale[:, None] * qp.A).contiguous()
             if self.obj_scale != 1.0:
                 self.H = None if qp.H is None else (self.obj_scale * qp.H).contiguous()
                 self.q = self.obj_scale * qp.q
@@ -334,7 +336,12 @@ class MPCSolver:
             extra = dict(panel_width=opt.panel_width)
         else:
             normal_cls, condensed_cls = HIPNormalKKTSystem, HIPCondensedKKTSystem
-        if opt.kkt_system == "normal":
+        if isinstance(self.A, DeviceCSR):  # sparse front end: dense K / Cholesky, CSR products
+            if opt.distributed:
+                raise ValueError("the sparse front end runs on one GPU")
+            cls = HIPSparseNormalKKTSystem if opt.kkt_system == "normal" else HIPSparseCondensedKKTSystem
+            self.kkt = cls(be, st, nx, self.ind_ineq, self.H, self.A)
+        elif opt.kkt_system == "normal":
             self.At = self.A.t().contiguous()  # (nx, m): the layout the normal-equations GEMM consumes
             self.kkt = normal_cls(be, st, nx, self.ind_ineq, self.H, self.At, **extra)
         else:

@@ -153,6 +153,27 @@ def synthetic_qp(seed: int, n: int, m: int, family: str = "wigner") -> DenseQP:
     )
 
 
+def sparse_qp(seed: int, n: int, m: int, per_row: int = 4, family: str = "wigner", equality_cons=()) -> DenseQP:
+    """The synthetic family with a SPARSE Jacobian (held dense here): row i keeps the Gaussian entries of
+    ``gen_A`` at ``per_row`` pseudo-random columns plus the band entry (i mod n), so that every row is
+    non-empty and columns overlap between rows (the Gram matrix A' Theta A is genuinely dense-ish).
+    ``equality_cons``: rows turned into equalities at their lower bound (Netlib-style LPs)."""
+    qp = synthetic_qp(seed, n, m, family)
+    mask = np.zeros((m, n), dtype=bool)
+    key = stream_key(seed, 7)
+    with np.errstate(over="ignore"):
+        idx = np.arange(m * per_row, dtype=np.uint64)
+        cols = (mix64(np.uint64(key) ^ idx) % np.uint64(n)).astype(np.int64).reshape(m, per_row)
+    for i in range(m):
+        mask[i, cols[i]] = True
+        mask[i, i % n] = True
+    qp.A = np.where(mask, qp.A, 0.0)
+    for j in equality_cons:
+        qp.ucon[j] = qp.lcon[j]
+    qp.name = f"sparse-{family}-n{n}-m{m}-s{seed}"
+    return qp
+
+
 def dummy_qp(n: int, m: int, seed: int = 1, equality_cons=()) -> DenseQP:
     """Small QP in the spirit of ``MadNLPTests.DenseDummyQP`` (``test/runtests.jl:9``).
 

@@ -1,0 +1,111 @@
+"""GPU: the sparse-A front end (reference: coo_to_csr / assemble_normal_system!,
+src/utils.jl:148-298, NormalKKTSystem constructor src/KKT/normalkkt.jl:51-101).  The Jacobian is CSR on
+the device, the factorised matrix stays dense: assembled matrix, products and whole solves must agree
+with the dense path of the same library and with the CPU oracle on the densified problem."""
+import numpy as np
+import pytest
+import torch
+
+import madqp_jl_amd as M
+from oracle import mpc
+from oracle import qp as Q
+
+pytestmark = pytest.mark.gpu
+REG = M.FixedRegularization(1e-8, -1e-8)
+
+
+def to_device(qp, be, sparse):
+    return M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0,
+                                 sparse=sparse)
+
+
+def close(a, b, tol):
+    return abs(a - b) <= tol * max(1.0, abs(a), abs(b))
+
+
+def lower(be, kkt, n):
+    ptr, ld = be.kkt_matrix(kkt._h, n)
+    return np.tril(be.read_doubles(ptr, ld * n).reshape(n, ld)[:, :n].T)
+
+
+def test_csr_container(hip):
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((7, 11)) * (rng.random((7, 11)) < 0.3)
+    A[3] = 0.0  # an empty row
+    c = M.DeviceCSR.from_dense(hip.device, A)
+    assert c.nnz == np.count_nonzero(A) and np.array_equal(c.to_dense().cpu().numpy(), A)
+    assert np.array_equal(c.row_absmax().cpu().numpy(), np.abs(A).max(axis=1))
+    # CSR of A' through the stored permutation
+    At = np.zeros((11, 7))
+    tp, tc, tv = (t.cpu().numpy() for t in (c.t_ptr, c.t_col, c.t_val))
+    for r in range(11):
+        At[r, tc[tp[r]:tp[r + 1]]] = tv[tp[r]:tp[r + 1]]
+    assert np.array_equal(At, A.T)
+    s = c.scaled(torch.arange(1, 8, dtype=torch.float64, device=hip.device))
+    assert np.array_equal(s.to_dense().cpu().numpy(), A * np.arange(1, 8)[:, None])
+    with pytest.raises(ValueError):
+        M.DeviceCSR(hip.device, 2, 2, [0, 0], [1, 1], [1.0, 2.0])
+
+
+@pytest.mark.parametrize("ksys,family", [("condensed", "wigner"), ("condensed", "lp"), ("normal", "lp")])
+def test_sparse_matches_dense_path(hip, ksys, family):
+    """Same library, Jacobian held sparse vs dense: assembled matrix, jtprod!, mul!, solve!."""
+    qp = Q.sparse_qp(21, 300, 130, 5, family, equality_cons=(3, 40) if ksys == "normal" else ())
+    reg = M.FixedRegularization(1e-8, 0.0) if ksys == "normal" else REG
+    solvers = []
+    for sparse in (False, True):
+        s = M.MPCSolver(to_device(qp, hip, sparse), hip, kkt_system=ksys, regularization=reg)
+        s.initialize()
+        hip.set_aug_diagonal_reg(s.st, 1e-8, reg.delta_d)
+        s.kkt.factorize_wrapper()
+        assert s.kkt.linear_solver.is_factorized()
+        solvers.append(s)
+    d, sp = solvers
+    assert type(sp.kkt).__name__.startswith("HIPSparse")
+    order = 130 if ksys == "normal" else 300
+    Kd, Ks = lower(hip, d.kkt, order), lower(hip, sp.kkt, order)  # factors of the same matrix
+    assert np.max(np.abs(Kd - Ks)) <= 1e-11 * np.max(np.abs(Kd))
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(d.st.ntot)
+    outs = []
+    for s in solvers:
+        st = s.st
+        st.p.copy_(torch.as_tensor(b))
+        hip.copy(st.p, st.d)
+        s.kkt.solve(st.d)
+        hip.fill(0.0, st.w1)
+        s.kkt.mul(st.w1, st.d, 1.0, 0.0)
+        s.kkt.jtprod(st.jacl, st.y)
+        outs.append((st.d.cpu().numpy().copy(), st.w1.cpu().numpy().copy(), st.jacl.cpu().numpy().copy()))
+    for a, c in zip(outs[0], outs[1]):
+        assert np.max(np.abs(a - c)) <= 1e-9 * max(1.0, np.max(np.abs(a)))
+    assert np.max(np.abs(outs[1][1] - b)) / np.max(np.abs(b)) < 1e-8  # K * solve(b) == b
+    for s in solvers:
+        s.close()
+
+
+@pytest.mark.parametrize("case", ["lp_normal", "lp_condensed", "qp_condensed", "lp_normal_native"])
+def test_sparse_solves_vs_oracle(hip, case):
+    if case.startswith("lp_normal"):
+        qp = Q.sparse_qp(31, 160, 70, 4, "lp", equality_cons=(2, 9, 33))
+        kw = dict(kkt_system="normal", regularization=M.FixedRegularization(1e-8, 0.0))
+        okw = dict(kkt_system="normal", regularization=mpc.FixedRegularization(1e-8, 0.0))
+    elif case == "lp_condensed":
+        qp = Q.sparse_qp(3, 100, 40, 6, "lp")  # (equality rows: Theta = 1e8 puts the condensed LP at 1e-8 accuracy)
+        kw, okw = dict(regularization=REG), dict(kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8))
+    else:
+        qp = Q.sparse_qp(3, 200, 60, 10)
+        kw, okw = dict(regularization=REG), dict(kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8))
+    if case.endswith("native"):
+        kw["driver"] = "native"
+    s = M.MPCSolver(to_device(qp, hip, True), hip, **kw)
+    r = s.solve()
+    s.close()
+    ref = mpc.solve(qp, **okw)
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"], (r["iter"], ref["iter"])
+    for t, g in zip(r["trace"], ref["trace"]):
+        tol = 1e-9 if min(t["mu"], g["mu"]) >= 1e-4 else 1e-6
+        for key in ("alpha_p", "alpha_d", "inf_pr", "inf_du", "mu"):
+            assert close(t[key], g[key], tol), (case, t["k"], key, t[key], g[key])
+    assert close(r["objective"], ref["objective"], 1e-9)
+    assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
