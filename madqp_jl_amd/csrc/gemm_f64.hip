@@ -52,6 +52,11 @@ struct KArgs {
     int32_t fast_ok;  // pointers / leading dimensions allow 16-byte loads
     int32_t xcd_remap;
     GemmBatch batch;  // B <= 1: single problem
+    // split-K (launches with fewer tiles than resident workgroups): blockIdx.y = split, each split
+    // covers kchunk of K and stores its raw 128 x 128 partial into work[(split * ntiles + t)]
+    int32_t ksplit;
+    int64_t kchunk;
+    double* work;
 #ifdef MADQP_STAMPS
     unsigned long long* stamps;  // diagnostic build only (tools/gemm_probe): per-workgroup clocks
 #endif
@@ -277,7 +282,12 @@ __device__ __forceinline__ void mainloop_dma(const GemmArgs& g, int64_t i0, int6
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_DOUBLES];
     GemmArgs g = ka.g;
-    if (ka.batch.B > 1) {  // wave-uniform pointer offsets of problem blockIdx.y
+    if (ka.ksplit > 1) {
+        const int64_t k0 = (int64_t)blockIdx.y * ka.kchunk;
+        g.X += k0 * g.ldx;
+        g.Y += k0 * g.ldy;
+        g.K = (g.K - k0 < ka.kchunk) ? (g.K - k0) : ka.kchunk;
+    } else if (ka.batch.B > 1) {  // wave-uniform pointer offsets of problem blockIdx.y
         const int64_t b = blockIdx.y;
         if (ka.batch.skip && ka.batch.skip[b] != 0) return;
         g.X += b * ka.batch.sX;
@@ -326,6 +336,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
     }
 #endif
     const int lo = lane & 15, hi = lane >> 4;
+    if (ka.ksplit > 1) {  // raw partial tile, column-major 128 x 128; the epilogue runs in splitk_reduce_kernel
+        double* W = ka.work + ((int64_t)blockIdx.y * ka.ntiles + t) * (BM * BN);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    W[(wj * 64 + tj * 16 + hi + 4 * v) * BM + wi * 64 + ti * 16 + lo] = acc[ti][tj][v];
+        return;
+    }
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
         const int64_t gi = i0 + wi * 64 + ti * 16 + lo;
@@ -342,6 +363,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
                 }
             }
         }
+    }
+}
+
+// C tile = epilogue(sum over the splits, in split order) -- deterministic two-pass split-K
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, const int32_t* __restrict__ table,
+                                                            int32_t ntiles, int32_t ksplit,
+                                                            const double* __restrict__ work) {
+    const int t = blockIdx.x;
+    const int32_t packed = table[t];
+    const int64_t i0 = (int64_t)(packed >> 16) * BM, j0 = (int64_t)(packed & 0xFFFF) * BN;
+    const int li = threadIdx.x & (BM - 1);
+    const int64_t gi = i0 + li;
+    for (int lj = threadIdx.x >> 7; lj < BN; lj += 2) {
+        const int64_t gj = j0 + lj;
+        if (gi >= g.M || gj >= g.N || (g.lower_only && gi + g.diag_off < gj)) continue;
+        double sum = 0.0;
+        for (int sp = 0; sp < ksplit; ++sp) sum += work[((int64_t)sp * ntiles + t) * (BM * BN) + lj * BM + li];
+        double val = g.alpha * sum;
+        if (g.Cin) val += g.beta * g.Cin[gi + gj * g.ldcin];
+        if (g.dvec && gi + g.diag_off == gj) val += g.dvec[gj];
+        g.C[gi + gj * g.ldc] = val;
     }
 }
 
@@ -462,8 +504,32 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
     static const int xcd_remap = getenv("MADQP_GEMM_XCD") ? atoi(getenv("MADQP_GEMM_XCD")) : 1;
     ka.xcd_remap = xcd_remap;
     ka.batch = batch ? *batch : GemmBatch{1, 0, 0, 0, 0, 0, nullptr};
-    const unsigned gy = (unsigned)std::max<int64_t>(1, ka.batch.B);
+    unsigned gy = (unsigned)std::max<int64_t>(1, ka.batch.B);
     ARG_TRY(ctx, gy <= 65535);
+    // Split-K: a launch with far fewer tiles than resident workgroups leaves most of the chip idle while
+    // each tile walks all of K alone (5k-20k matrices, the last panels of a large one).  Cut K into up
+    // to 16 chunks of >= 256, one workgroup per (tile, chunk), partials summed in chunk order by a second
+    // small kernel: same result on every run.
+    static const int split_on = getenv("MADQP_GEMM_SPLITK") ? atoi(getenv("MADQP_GEMM_SPLITK")) : 1;
+    ka.ksplit = 1;
+    ka.kchunk = a.K;
+    ka.work = nullptr;
+    if (split_on && !batch && (int64_t)ka.ntiles * 2 <= ctx->gemm_slots && a.K >= 512) {
+        int64_t S = std::min<int64_t>(std::min<int64_t>(ctx->gemm_slots / ka.ntiles, a.K / 256), 16);
+        if (S >= 2) {
+            const int64_t chunk = ((a.K + S - 1) / S + BK - 1) / BK * BK;
+            S = (a.K + chunk - 1) / chunk;
+            if (S >= 2) {
+                const size_t bytes = (size_t)S * ka.ntiles * BM * BN * sizeof(double);
+                int32_t r = madqp_work_reserve(ctx, bytes);
+                if (r) return r;
+                ka.ksplit = (int32_t)S;
+                ka.kchunk = chunk;
+                ka.work = ctx->d_work;
+                gy = (unsigned)S;
+            }
+        }
+    }
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     ka.fast_ok = al16(a.X) && al16(a.Y) && (a.ldx % 2 == 0) && (a.ldy % 2 == 0);
 #ifdef MADQP_STAMPS
@@ -488,6 +554,11 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
         hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3(ka.ntiles, gy), dim3(NTHREADS), 0, ctx->stream, ka);
         LAUNCH_CHECK(ctx);
         if (cnt == total - off) break;
+    }
+    if (ka.ksplit > 1) {  // (a split launch is always a single segment: few tiles)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(total), dim3(256), 0, ctx->stream, a, table0, total, ka.ksplit,
+                           ka.work);
+        LAUNCH_CHECK(ctx);
     }
     return MADQP_OK;
 }
