@@ -12,8 +12,10 @@
 //       L_jj = chol(C_jj),  W_jj = L_jj^-1                   one workgroup, block resident in LDS
 //       L[jb+128:n, jb] = C[jb+128:n, jb] * W_jj'            gemm core, K = N = 128        (MFMA)
 // The inverse diagonal blocks W are kept (two images, 2 x n x 128 doubles) and turn the diagonal
-// solves of the two triangular sweeps into 128 x 128 mat-vecs; the sweeps are HBM bound
-// (4 n^2 bytes each).
+// solves of the two triangular sweeps into 128 x 128 mat-vecs; each sweep is ONE launch of
+// ticket-ordered workgroups handing the solved blocks on through a sentinel-tagged vector, HBM bound
+// (4 n^2 bytes).  Also here: the same factorisation for a batch of small matrices
+// (madqp_chol_factor_batched) and its pieces for the multi-GPU panel loop (madqp_chol_factor_panel, ...).
 #include <algorithm>
 #include <cstdlib>
 
