@@ -195,6 +195,18 @@ def test_full_size_properties_n5k(hip):
     assert np.all(x >= -1e-7) and np.all(x <= 1 + 1e-7)
     Ax = (dq.A @ torch.as_tensor(x, device=hip.device)).cpu().numpy()
     assert np.all(Ax >= -1e-6) and np.all(Ax <= 1 + 1e-6)
+    # optimality certificate from the returned primal-dual point alone (no oracle, no solver):
+    # H x + q + A'y - zl + zu = 0, multipliers of the right sign, complementary to their constraints
+    xd = torch.as_tensor(x, device=hip.device)
+    y, zl, zu = (torch.as_tensor(r[k], device=hip.device) for k in ("multipliers", "multipliers_L", "multipliers_U"))
+    g = dq.H @ xd + dq.q
+    scale = max(1.0, float(g.abs().max()))
+    assert float((g + dq.A.t() @ y - zl + zu).abs().max()) <= 1e-6 * scale
+    assert float(zl.min()) >= -1e-8 and float(zu.min()) >= -1e-8
+    assert float((zl * xd).abs().max()) <= 1e-6 * scale and float((zu * (1 - xd)).abs().max()) <= 1e-6 * scale
+    Axd = torch.as_tensor(Ax, device=hip.device)
+    assert float((y.clamp(min=0) * (1 - Axd)).abs().max()) <= 1e-6 * scale
+    assert float((y.clamp(max=0) * Axd).abs().max()) <= 1e-6 * scale
     s.kkt.close()
 
 

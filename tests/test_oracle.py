@@ -154,3 +154,58 @@ def test_golden_traces_are_reproduced():
         for a, b in zip(cur["trace"], golden[name]["trace"]):
             for k in make_golden.KEYS:
                 assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (name, a["k"], k)
+
+
+def kkt_certificate(qp, r, tol):
+    """Optimality conditions of  min c0 + q'x + x'Hx/2, lcon <= Ax <= ucon, lvar <= x <= uvar  checked from the
+    returned primal-dual point alone (sign conventions of MadNLP: grad + A'y - zl + zu = 0, zl, zu >= 0)."""
+    x, y, zl, zu = r["solution"], r["multipliers"], r["multipliers_L"], r["multipliers_U"]
+    amax = lambda v: float(np.max(np.abs(v), initial=0.0))
+    g = qp.H @ x + qp.q
+    scale = max(1.0, np.max(np.abs(g)))
+    assert amax(g + qp.A.T @ y - zl + zu) <= tol * scale  # stationarity
+    ax = qp.A @ x
+    assert np.all(x >= qp.lvar - tol) and np.all(x <= qp.uvar + tol)
+    assert np.all(ax >= qp.lcon - tol) and np.all(ax <= qp.ucon + tol)
+    assert np.all(zl >= -tol) and np.all(zu >= -tol)
+    fin = lambda v: np.where(np.isfinite(v), v, 0.0)
+    assert amax(zl * fin(x - qp.lvar)) <= tol * scale and amax(zu * fin(qp.uvar - x)) <= tol * scale
+    # constraint multipliers: y_i > 0 only at the upper side, y_i < 0 only at the lower side
+    assert amax(np.maximum(y, 0.0) * fin(qp.ucon - ax)) <= tol * scale
+    assert amax(np.minimum(y, 0.0) * fin(ax - qp.lcon)) <= tol * scale
+
+
+def test_box_qp_has_the_closed_form_solution():
+    """Separable box QP: x* = clip(-q/h, l, u) -- no solver in the loop."""
+    rng = np.random.default_rng(7)
+    n = 40
+    h, q = rng.uniform(0.5, 3.0, n), rng.standard_normal(n) * 2
+    qp = Q.DenseQP(H=np.diag(h), q=q, A=np.zeros((0, n)), lvar=-np.ones(n), uvar=np.ones(n), lcon=np.zeros(0),
+                   ucon=np.zeros(0), x0=np.zeros(n), name="box")
+    xs = np.clip(-q / h, -1.0, 1.0)
+    for kkt in ("K2", "condensed"):
+        r = mpc.solve(qp, kkt_system=kkt, regularization=REG())
+        assert r["status"] == mpc.SOLVE_SUCCEEDED
+        assert np.max(np.abs(r["solution"] - xs)) < 1e-6
+        assert abs(r["objective"] - (0.5 * xs @ (h * xs) + q @ xs)) < 1e-6  # tol = 1e-8 on scaled residuals
+        kkt_certificate(qp, r, 1e-6)
+
+
+@pytest.mark.parametrize("make", [lambda: Q.synthetic_qp(11, 30, 12), lambda: Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)),
+                                  lambda: Q.hs21(), lambda: Q.synthetic_qp(12, 25, 10, "lp")])
+def test_solutions_carry_an_optimality_certificate(make):
+    """KKT conditions checked from the returned point alone, and the objective against scipy's
+    independent trust-constr solver."""
+    qp = make()
+    r = mpc.solve(qp, kkt_system="condensed", regularization=REG())
+    assert r["status"] == mpc.SOLVE_SUCCEEDED
+    kkt_certificate(qp, r, 2e-6)
+    cons = so.LinearConstraint(qp.A, qp.lcon, qp.ucon)
+    res = so.minimize(lambda x: qp.c0 + qp.q @ x + 0.5 * x @ qp.H @ x, np.clip(qp.x0, qp.lvar, qp.uvar),
+                      jac=lambda x: qp.q + qp.H @ x, hess=lambda x: qp.H, method="trust-constr",
+                      bounds=so.Bounds(qp.lvar, qp.uvar), constraints=[cons],
+                      options=dict(gtol=1e-10, xtol=1e-12, maxiter=3000))
+    # trust-constr stops at a barrier parameter of ~1e-5: it agrees to that accuracy and is never better than
+    # the certified point
+    assert abs(res.fun - r["objective"]) <= 1e-3 * max(1.0, abs(r["objective"]))
+    assert res.fun >= r["objective"] - 1e-6 * max(1.0, abs(r["objective"]))
