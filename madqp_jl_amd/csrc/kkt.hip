@@ -318,7 +318,7 @@ extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* 
 extern "C" int32_t madqp_kkt_jtprod(madqp_kkt* k, double* out, const double* y) {
     if (!k) return MADQP_ERR_ARG;
     madqp_ctx* ctx = k->ctx;
-    ARG_TRY(ctx, (out && y) || (k->nx + k->ns == 0));
+    ARG_TRY(ctx, (out || k->nx + k->ns == 0) && (y || k->m == 0));  // no constraints: y is empty
     int32_t r;
     if ((r = apply_At(k, 1.0, y, 0.0, out))) return r;
     if (k->ns) {

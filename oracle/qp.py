@@ -174,6 +174,31 @@ def sparse_qp(seed: int, n: int, m: int, per_row: int = 4, family: str = "wigner
     return qp
 
 
+def random_qp(seed: int, n: int, m: int, lp: bool = False, pattern_seed=None) -> DenseQP:
+    """Feasible dense QP / LP with a RANDOM pattern of bounds: variables free / lower / upper / boxed,
+    rows equality / >= / <= / ranged (test generator: exercises ind_lb != ind_ub, free variables, one-sided
+    rows -- the synthetic family has every bound finite).  ``pattern_seed`` fixes which bounds are finite
+    independently of the data (batches need one pattern).  numpy Generator, CPU only."""
+    rng = np.random.default_rng(seed)
+    prng = np.random.default_rng(seed if pattern_seed is None else pattern_seed)
+    R = rng.standard_normal((n, n))
+    H = np.zeros((n, n)) if lp else R @ R.T / n + np.eye(n)
+    A = rng.standard_normal((m, n))
+    xf = rng.uniform(-1.0, 1.0, n)  # a strictly feasible point
+    kind = prng.integers(0, 4, n)
+    lvar = np.where((kind == 1) | (kind == 3), xf - rng.uniform(0.5, 2.0, n), -np.inf)
+    uvar = np.where((kind == 2) | (kind == 3), xf + rng.uniform(0.5, 2.0, n), np.inf)
+    if lp:  # keep the LP bounded
+        lvar = np.where(np.isfinite(lvar), lvar, xf - 3.0)
+        uvar = np.where(np.isfinite(uvar), uvar, xf + 3.0)
+    ax = A @ xf
+    ck = prng.integers(0, 4, m)
+    lcon = np.where(ck == 0, ax, np.where((ck == 1) | (ck == 3), ax - rng.uniform(0.1, 1.0, m), -np.inf))
+    ucon = np.where(ck == 0, ax, np.where((ck == 2) | (ck == 3), ax + rng.uniform(0.1, 1.0, m), np.inf))
+    return DenseQP(H=H, q=rng.standard_normal(n), A=A, lvar=lvar, uvar=uvar, lcon=lcon, ucon=ucon,
+                   x0=np.zeros(n), name=f"random-n{n}-m{m}-s{seed}")
+
+
 def dummy_qp(n: int, m: int, seed: int = 1, equality_cons=()) -> DenseQP:
     """Small QP in the spirit of ``MadNLPTests.DenseDummyQP`` (``test/runtests.jl:9``).
 

@@ -1,0 +1,61 @@
+"""GPU: randomised bound patterns (free / one-sided / boxed variables; equality / >= / <= / ranged rows) through
+every driver of the library against the CPU oracle.  The synthetic family of the benchmark has every bound
+finite; here ind_lb != ind_ub, slack bounds are one-sided and some rows are equalities."""
+import numpy as np
+import pytest
+
+import madqp_jl_amd as M
+from oracle import mpc
+from oracle import qp as Q
+
+pytestmark = pytest.mark.gpu
+REG, OREG = M.FixedRegularization(1e-8, -1e-8), mpc.FixedRegularization(1e-8, -1e-8)
+CASES = [(1, 5, 3, False), (2, 17, 9, False), (3, 40, 25, False), (4, 64, 10, True), (5, 130, 70, False),
+         (6, 200, 90, True), (7, 33, 0, False), (8, 1, 1, False), (9, 90, 60, False), (10, 257, 120, False)]
+
+
+def to_device(qp, be, sparse=False):
+    return M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0,
+                                 sparse=sparse)
+
+
+def same(r, ref, what):
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED, (what, r["status"], ref["status"])
+    assert r["iter"] == ref["iter"], (what, r["iter"], ref["iter"])
+    assert abs(r["objective"] - ref["objective"]) <= 1e-8 * max(1.0, abs(ref["objective"])), what
+    assert np.max(np.abs(r["solution"] - ref["solution"]), initial=0.0) <= 1e-6, what
+    assert np.max(np.abs(r["multipliers"] - ref["multipliers"]), initial=0.0) <= 1e-5, what
+
+
+@pytest.mark.parametrize("seed,n,m,lp", CASES)
+def test_random_patterns_all_drivers(hip, seed, n, m, lp):
+    qp = Q.random_qp(seed, n, m, lp)
+    ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG)
+    for driver in ("python", "native"):
+        s = M.MPCSolver(to_device(qp, hip), hip, regularization=REG, driver=driver)
+        same(s.solve(), ref, driver)
+        s.close()
+    if m and n > 1:  # the same problem with the Jacobian handed over as CSR
+        s = M.MPCSolver(to_device(qp, hip, sparse=True), hip, regularization=REG)
+        same(s.solve(), ref, "sparse front end")
+        s.close()
+    b = M.BatchedMPCSolver([to_device(qp, hip)], hip, regularization=REG)
+    same(b.solve()[0], ref, "batched engine, B = 1")
+    b.close()
+    if lp:  # the reference's own formulation (normal equations, delta_d = 0), dense and CSR Jacobian
+        nref = mpc.solve(qp, kkt_system="normal", regularization=mpc.FixedRegularization(1e-8, 0.0))
+        for sparse in (False, True):
+            s = M.MPCSolver(to_device(qp, hip, sparse=sparse), hip, kkt_system="normal",
+                            regularization=M.FixedRegularization(1e-8, 0.0))
+            same(s.solve(), nref, f"normal equations, sparse={sparse}")
+            s.close()
+
+
+def test_random_patterns_batched(hip):
+    """One bound pattern, different data: a batch of 9 against the oracle, problem by problem."""
+    qps = [Q.random_qp(300 + i, 48, 30, pattern_seed=77) for i in range(9)]
+    b = M.BatchedMPCSolver([to_device(q, hip) for q in qps], hip, regularization=REG)
+    res = b.solve(check_every=2)
+    b.close()
+    for i, (qp, r) in enumerate(zip(qps, res)):
+        same(r, mpc.solve(qp, kkt_system="condensed", regularization=OREG), f"batch member {i}")
