@@ -768,6 +768,7 @@ class MPCSolver:
             multipliers=self.y * self.con_scale / self.obj_scale,
             multipliers_L=self.zl[: self.nx] / self.obj_scale,
             multipliers_U=self.zu[: self.nx] / self.obj_scale,
+            n_factorizations=self.kkt.n_factorizations,
             trace=self.trace,
         )
 

@@ -30,7 +30,7 @@ def test_two_ranks_gloo(tmp_path):
     assert len(lines) == 1, "only rank 0 prints the JSON line"
 
 
-@pytest.mark.parametrize("world,n,nb,port", [(2, 700, 128, 29519), (3, 1000, 256, 29521)])
+@pytest.mark.parametrize("world,n,nb,port", [(2, 700, 128, 29519), (3, 1000, 256, 29521), (2, 400, 512, 29523)])
 def test_distributed_cholesky_orchestration(tmp_path, world, n, nb, port):
     """SURVEY.md 8e, one dense KKT over N ranks: the panel-cyclic right-looking driver (dist.py) over
     gloo with numpy stand-ins for the rank-local kernels gives the Cholesky factor on every rank, ships
@@ -49,7 +49,8 @@ def test_distributed_cholesky_orchestration(tmp_path, world, n, nb, port):
         assert rec["factored"] == [p * nb for p in range(npan) if p % world == r]  # own panels, in order
         # each owned panel q receives exactly one update from every panel to its left
         assert rec["updates"] == sum(q for q in range(npan) if q % world == r)
-        assert rec["not_pd_info"] == 301  # first failing column (1-based), identical on all ranks
+        assert rec["not_pd_info"] == 301  # first failing column (1-based), identical on all ranks (also when
+        # the whole matrix is one panel and rank 1 owns nothing)
         assert rec["default_nb"] == [1024, 256, 256]
     total = sum(rec["bytes_sent"] for rec in recs)
     assert total == 8 * sum(2 + min(nb, n - j) * (n - j) for j in range(0, n, nb))  # each panel sent once

@@ -178,6 +178,27 @@ def test_factorization_failure_is_a_return_code(hip):
     s.kkt.close()
 
 
+@DRIVERS
+def test_regularization_retry_succeeds(hip, driver):
+    """src/linear_solver.jl:6-17 on the device: with a slightly indefinite H and a free variable, the
+    factorisation fails at delta_w = 1e-8, succeeds at 1e-6; the retry count and the trace follow the oracle.
+    max_iter is honoured (status 6) by both drivers."""
+    qp, free = Q.synthetic_qp(8, 20, 8), 3
+    qp.lvar[free], qp.uvar[free] = -np.inf, np.inf
+    qp.H = np.diag(np.diag(qp.H))  # diagonal H: K_ii of the free variable is H_ii + delta_w + (A' Theta A)_ii
+    qp.A[:, free] = 0.0
+    qp.H[free, free] = -1e-7
+    qp.q[free] = 0.0
+    kw = dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_iter=4, driver=driver)
+    s = M.MPCSolver(to_device(qp, hip), hip, **kw)
+    r = s.solve()
+    ref = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8), max_iter=4)
+    assert r["status"] == ref["status"] == M.MAXIMUM_ITERATIONS_EXCEEDED and r["iter"] == ref["iter"] == 4
+    assert r["n_factorizations"] == ref["n_factorizations"] > r["iter"] + 1  # retries happened
+    compare_traces(r["trace"], ref["trace"], "retry")
+    s.close()
+
+
 def test_full_size_properties_n5k(hip):
     """BASELINE config 1 (n=5000, m=2000) is beyond what the oracle finishes in seconds:
     size-independent properties.  The condensed solve must satisfy the UNREDUCED KKT system
