@@ -135,6 +135,12 @@ struct madqp_batch {
     BQ q;
     std::vector<void*> owned;
     int32_t* d_active;
+    // one lock-step iteration (13 launches) captured once as a hipGraph and replayed on an internal stream
+    hipStream_t sG = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t evIn = nullptr, evOut = nullptr;
+    int graph_state = 0;  // 0 not tried, 1 ready, -1 unavailable
     bool wide;  // 512 threads per problem (small batches)
 };
 
@@ -195,6 +201,12 @@ int32_t factor_all(madqp_batch* b) {
 extern "C" int32_t madqp_batch_destroy(madqp_batch* b) {
     if (!b) return MADQP_OK;
     (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->sG) (void)hipStreamSynchronize(b->sG);
+    if (b->exec) (void)hipGraphExecDestroy(b->exec);
+    if (b->graph) (void)hipGraphDestroy(b->graph);
+    if (b->evIn) (void)hipEventDestroy(b->evIn);
+    if (b->evOut) (void)hipEventDestroy(b->evOut);
+    if (b->sG) (void)hipStreamDestroy(b->sG);
     for (void* p : b->owned) (void)hipFree(p);
     delete b;
     return MADQP_OK;
@@ -332,6 +344,64 @@ extern "C" int32_t madqp_batch_init(madqp_batch* b, double mu_init, double bound
     return MADQP_OK;
 }
 
+// one lock-step iteration on ctx->stream: loop head + operands, assembly + Cholesky, the rest
+static int32_t launch_iteration(madqp_batch* b) {
+    madqp_ctx* ctx = b->ctx;
+    const BQ& q = b->q;
+    {
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        if (b->wide)
+            hipLaunchKernelGGL(wg512::bq_iter_pre_kernel, dim3((unsigned)q.B), dim3(512), 0, ctx->stream, q);
+        else
+            hipLaunchKernelGGL(wg256::bq_iter_pre_kernel, dim3((unsigned)q.B), dim3(256), 0, ctx->stream, q);
+        LAUNCH_CHECK(ctx);
+    }
+    int32_t r = factor_all(b);
+    if (r) return r;
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    const bool gz = q.opt.max_ncorr > 0;
+    if (b->wide && gz)
+        hipLaunchKernelGGL(wg512::bq_iter_post_kernel<true>, dim3((unsigned)q.B), dim3(512), 0, ctx->stream, q);
+    else if (b->wide)
+        hipLaunchKernelGGL(wg512::bq_iter_post_kernel<false>, dim3((unsigned)q.B), dim3(512), 0, ctx->stream, q);
+    else if (gz)
+        hipLaunchKernelGGL(wg256::bq_iter_post_kernel<true>, dim3((unsigned)q.B), dim3(256), 0, ctx->stream, q);
+    else
+        hipLaunchKernelGGL(wg256::bq_iter_post_kernel<false>, dim3((unsigned)q.B), dim3(256), 0, ctx->stream, q);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
+
+// Captures launch_iteration into a graph (MADQP_BATCH_GRAPH=0: off).  The launches are identical from one
+// iteration to the next (problems drop out through their status words, not through the grid), the tile
+// tables they need exist since madqp_batch_init, and nothing in between touches the host.
+static bool graph_ready(madqp_batch* b) {
+    static const int enabled = getenv("MADQP_BATCH_GRAPH") ? atoi(getenv("MADQP_BATCH_GRAPH")) : 1;
+    madqp_ctx* ctx = b->ctx;
+    if (!enabled || ctx->prof != 0 || b->graph_state < 0) return false;  // profiling events are not capturable
+    if (b->graph_state == 1) return true;
+    b->graph_state = -1;
+    if (hipStreamCreateWithFlags(&b->sG, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&b->evIn, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&b->evOut, hipEventDisableTiming) != hipSuccess) return false;
+    (void)hipStreamSynchronize(ctx->stream);
+    hipStream_t saved = ctx->stream;
+    ctx->stream = b->sG;
+    bool ok = hipStreamBeginCapture(b->sG, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        const int32_t r = launch_iteration(b);
+        const hipError_t e = hipStreamEndCapture(b->sG, &b->graph);
+        ok = (r == MADQP_OK) && (e == hipSuccess) && b->graph;
+    }
+    ctx->stream = saved;
+    if (ok) ok = hipGraphInstantiate(&b->exec, b->graph, nullptr, nullptr, 0) == hipSuccess;
+    (void)hipGetLastError();  // a failed capture must not poison later launch checks
+    if (getenv("MADQP_BATCH_GRAPH_VERBOSE")) fprintf(stderr, "madqp batch graph: %s\n", ok ? "captured" : "capture failed, direct launches");
+    if (!ok) return false;
+    b->graph_state = 1;
+    return true;
+}
+
 // Up to max_steps lock-step iterations of mpc! (src/solver.jl:254-345); stops as soon as no problem
 // is active (checked every `check_every` steps with one 4-byte read-back).  n_active_host: problems
 // still active on return.
@@ -341,46 +411,37 @@ extern "C" int32_t madqp_batch_iterate(madqp_batch* b, int32_t max_steps, int32_
     madqp_ctx* ctx = b->ctx;
     ARG_TRY(ctx, max_steps >= 0 && check_every >= 1 && n_active_host);
     const BQ& q = b->q;
-    int32_t active = -1;
-    for (int32_t it = 0; it < max_steps; ++it) {
-        {
-            ProfScope ps(ctx, MADQP_PROF_VEC);
-            if (b->wide)
-                hipLaunchKernelGGL(wg512::bq_iter_pre_kernel, dim3((unsigned)q.B), dim3(512), 0, ctx->stream, q);
-            else
-                hipLaunchKernelGGL(wg256::bq_iter_pre_kernel, dim3((unsigned)q.B), dim3(256), 0, ctx->stream, q);
-            LAUNCH_CHECK(ctx);
-        }
-        int32_t r = factor_all(b);
-        if (r) return r;
-        {
-            ProfScope ps(ctx, MADQP_PROF_VEC);
-            const bool gz = q.opt.max_ncorr > 0;
-            if (b->wide && gz)
-                hipLaunchKernelGGL(wg512::bq_iter_post_kernel<true>, dim3((unsigned)q.B), dim3(512), 0, ctx->stream, q);
-            else if (b->wide)
-                hipLaunchKernelGGL(wg512::bq_iter_post_kernel<false>, dim3((unsigned)q.B), dim3(512), 0, ctx->stream, q);
-            else if (gz)
-                hipLaunchKernelGGL(wg256::bq_iter_post_kernel<true>, dim3((unsigned)q.B), dim3(256), 0, ctx->stream, q);
-            else
-                hipLaunchKernelGGL(wg256::bq_iter_post_kernel<false>, dim3((unsigned)q.B), dim3(256), 0, ctx->stream, q);
-            LAUNCH_CHECK(ctx);
-        }
-        if ((it + 1) % check_every == 0 || it + 1 == max_steps) {
-            hipLaunchKernelGGL(bq_count_active_kernel, dim3(1), dim3(64), 0, ctx->stream, q.status, q.B,
-                               b->d_active);
-            LAUNCH_CHECK(ctx);
-            HIP_TRY(ctx, hipMemcpyAsync(&active, b->d_active, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (active == 0) break;
-        }
+    const bool graph = max_steps > 0 && graph_ready(b);
+    hipStream_t st = graph ? b->sG : ctx->stream;
+    if (graph) {
+        HIP_TRY(ctx, hipEventRecord(b->evIn, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(b->sG, b->evIn, 0));
     }
-    if (active < 0) {
-        hipLaunchKernelGGL(bq_count_active_kernel, dim3(1), dim3(64), 0, ctx->stream, q.status, q.B, b->d_active);
+    auto count_active = [&](int32_t* active) -> int32_t {
+        hipLaunchKernelGGL(bq_count_active_kernel, dim3(1), dim3(64), 0, st, q.status, q.B, b->d_active);
         LAUNCH_CHECK(ctx);
-        HIP_TRY(ctx, hipMemcpyAsync(&active, b->d_active, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(active, b->d_active, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        return MADQP_OK;
+    };
+    int32_t active = -1, r = MADQP_OK;
+    for (int32_t it = 0; it < max_steps && !r; ++it) {
+        if (graph) {
+            if (hipGraphLaunch(b->exec, b->sG) != hipSuccess) r = madqp_fail(ctx, MADQP_ERR_HIP, "hipGraphLaunch failed");
+        } else {
+            r = launch_iteration(b);
+        }
+        if (!r && ((it + 1) % check_every == 0 || it + 1 == max_steps)) {
+            r = count_active(&active);
+            if (!r && active == 0) break;
+        }
     }
+    if (!r && active < 0) r = count_active(&active);
+    if (graph) {  // later work on the context's stream is ordered after the replays
+        (void)hipEventRecord(b->evOut, b->sG);
+        (void)hipStreamWaitEvent(ctx->stream, b->evOut, 0);
+    }
+    if (r) return r;
     *n_active_host = active;
     return MADQP_OK;
 }
