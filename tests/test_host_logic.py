@@ -158,3 +158,32 @@ def test_batch_sharding_is_a_partition():
         owned = [M.shard(range(37), r, world) for r in range(world)]
         assert sorted(sum(owned, [])) == list(range(37))
         assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1
+
+
+def test_device_csr_container_on_cpu():
+    """Host logic of the sparse front end (madqp_jl_amd/qp.py: DeviceCSR): CSR of A, CSR of A' through the stored
+    permutation, row scaling that follows the values, row maxima, duplicate detection."""
+    import torch
+
+    from madqp_jl_amd.qp import DeviceCSR
+
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((9, 13)) * (rng.random((9, 13)) < 0.3)
+    A[4] = 0.0
+    A[:, 6] = 0.0  # an empty row and an empty column
+    c = DeviceCSR.from_dense("cpu", A)
+    assert c.nnz == np.count_nonzero(A) and np.array_equal(c.to_dense().numpy(), A)
+    ptr, col = c.ptr.numpy(), c.col.numpy()
+    assert all(np.all(np.diff(col[ptr[r]:ptr[r + 1]]) > 0) for r in range(9))  # ascending within a row
+    assert np.array_equal(c.row_absmax().numpy(), np.abs(A).max(axis=1))
+    At = np.zeros((13, 9))
+    tp, tc, tv = c.t_ptr.numpy(), c.t_col.numpy(), c.t_val.numpy()
+    for r in range(13):
+        At[r, tc[tp[r]:tp[r + 1]]] = tv[tp[r]:tp[r + 1]]
+    assert np.array_equal(At, A.T)
+    scale = torch.arange(1, 10, dtype=torch.float64)
+    s = c.scaled(scale)
+    assert np.array_equal(s.to_dense().numpy(), A * np.arange(1, 10)[:, None]) and s.ptr is c.ptr
+    assert np.array_equal(s.t_val.numpy(), (A * np.arange(1, 10)[:, None]).T[np.nonzero(A.T)])
+    with pytest.raises(ValueError):
+        DeviceCSR("cpu", 2, 2, [0, 0], [1, 1], [1.0, 2.0])
