@@ -109,3 +109,35 @@ def test_sparse_solves_vs_oracle(hip, case):
             assert close(t[key], g[key], tol), (case, t["k"], key, t[key], g[key])
     assert close(r["objective"], ref["objective"], 1e-9)
     assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+
+
+def test_instance_file_to_gpu_pipeline(hip):
+    """The reference's benchmark pipeline (scripts/benchmarks_cpu.jl:17-55) on the device: instance text ->
+    read_qps -> scale_qp -> standard_form_qp -> sparse front end -> MPCSolver -> the nine recorded numbers.
+    HS21: objective -99.96 at (2, 0); an LP in standard form through the reference's own normal equations."""
+    from madqp_jl_amd import preprocess as P
+    from tests.test_preprocess import HS21_QPS
+
+    qp = P.read_qps(HS21_QPS)
+    scaled, Dr, Dc = P.ruiz_scale(qp)
+    s = M.MPCSolver(P.to_device(scaled, hip), hip, regularization=REG)
+    r = s.solve()
+    s.close()
+    assert r["status"] == M.SOLVE_SUCCEEDED and abs(r["objective"] + 99.96) < 1e-6
+    assert np.allclose(r["solution"] / Dc, [2.0, 0.0], atol=1e-6)
+    row = P.benchmark_row(scaled, r, 1.0, 0.5)
+    assert row[:6] == (2, 1, 2, 2, 1, r["iter"])
+    # LP: random feasible LP -> standard form (all rows equalities, x + w = xu rows) -> normal equations
+    lp = Q.random_qp(6, 40, 18, lp=True)
+    import scipy.sparse as sp
+
+    h = P.HostQP(lp.c0, lp.q, sp.csr_matrix((40, 40)), sp.csr_matrix(lp.A), lp.lvar, lp.uvar, lp.lcon, lp.ucon)
+    sf = P.standard_form(h)
+    assert np.array_equal(sf.lcon, sf.ucon)  # every row of the standard form is an equality
+    s = M.MPCSolver(P.to_device(sf, hip), hip, kkt_system="normal", regularization=M.FixedRegularization(1e-8, 0.0))
+    r = s.solve()
+    s.close()
+    ref = mpc.solve(lp, kkt_system="K2", regularization=mpc.FixedRegularization(1e-8, -1e-8))
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
+    assert abs(r["objective"] - ref["objective"]) <= 1e-6 * max(1.0, abs(ref["objective"]))
+    assert np.max(np.abs(r["solution"][:40] - ref["solution"])) < 1e-5

@@ -1,0 +1,186 @@
+"""CPU: the step in front of the path (madqp_jl_amd/preprocess.py; reference: scripts/common.jl): QPS reader,
+Ruiz scaling, standard form.  Pins: hand-written instance files of problems with known models / optima
+(HS21 of Maros-Meszaros, the simple LP of test/runtests.jl:24-55), structural identities of
+scripts/common.jl:109-288 and equivalence of the optima before / after each transformation (oracle)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from madqp_jl_amd import preprocess as P
+from oracle import mpc
+from oracle import qp as Q
+
+HS21_QPS = """NAME          HS21
+ROWS
+ N  OBJ.FUNC
+ G  R------1
+COLUMNS
+    C------1  R------1  0.100000e+02
+    C------2  R------1  -.100000e+01
+RHS
+    RHS1      OBJ.FUNC  0.100000e+03
+    RHS1      R------1  0.100000e+02
+RANGES
+BOUNDS
+ LO BOUNDS    C------1  0.200000e+01
+ UP BOUNDS    C------1  0.500000e+02
+ LO BOUNDS    C------2  -.500000e+02
+ UP BOUNDS    C------2  0.500000e+02
+QUADOBJ
+    C------1  C------1  0.200000e-01
+    C------2  C------2  0.200000e+01
+ENDATA
+"""
+
+MIXED_MPS = """* free format, every row / bound flavour
+NAME MIXED
+OBJSENSE
+    MAX
+ROWS
+ N COST
+ N SPARE
+ E EQ1
+ L LE1
+ G GE1
+ E EQR
+ L LER
+ G GER
+COLUMNS
+ X1 COST 1.0 EQ1 1.0
+ X1 LE1 2.0 SPARE 9.0
+ MARKER 'MARKER' 'INTORG'
+ X2 COST -2.0 GE1 1.0
+ X2 EQR 1.0
+ MARKER 'MARKER' 'INTEND'
+ X3 LER 1.0 GER -1.0
+ X4 EQ1 3.0
+ X5 COST 0.5
+ X6 LE1 1.0
+RHS
+ B EQ1 4.0 LE1 10.0
+ B GE1 -1.0 EQR 2.0
+ B LER 5.0 GER 1.0
+ B COST -7.0
+RANGES
+ R EQR -3.0 LER 2.0
+ R GER 4.0
+BOUNDS
+ UP BND X1 4.0
+ UP BND X2 -1.0
+ LO BND X3 -5.0
+ FX BND X4 2.5
+ FR BND X5
+ MI BND X6
+ENDATA
+"""
+
+
+def dense(qp):
+    return Q.DenseQP(H=qp.H.toarray(), q=qp.c, A=qp.A.toarray(), lvar=qp.lvar, uvar=qp.uvar, lcon=qp.lcon,
+                     ucon=qp.ucon, x0=qp.x0, c0=qp.c0, name=qp.name)
+
+
+def solve(qp, **kw):
+    kw.setdefault("regularization", mpc.FixedRegularization(1e-8, -1e-8))
+    return mpc.solve(dense(qp), kkt_system="condensed", **kw)
+
+
+def test_reader_hs21_known_model_and_optimum(tmp_path):
+    qp = P.read_qps(HS21_QPS)
+    ref = Q.hs21()
+    assert qp.name == "HS21" and qp.nvar == 2 and qp.ncon == 1 and qp.nnzj == 2 and qp.nnzh == 2
+    assert np.array_equal(qp.H.toarray(), ref.H) and np.array_equal(qp.c, ref.q) and qp.c0 == ref.c0 == -100.0
+    assert np.array_equal(qp.A.toarray(), ref.A)
+    for k in ("lvar", "uvar", "lcon", "ucon"):
+        assert np.array_equal(getattr(qp, k), getattr(ref, k)), k
+    r = solve(qp)
+    assert r["status"] == mpc.SOLVE_SUCCEEDED and abs(r["objective"] + 99.96) < 1e-7
+    # from a (gzipped) file, as import_mps does (scripts/common.jl:21-36)
+    import gzip
+
+    path = tmp_path / "HS21.SIF.gz"
+    with gzip.open(path, "wt") as f:
+        f.write(HS21_QPS)
+    q2 = P.read_qps(str(path))
+    assert np.array_equal(q2.A.toarray(), qp.A.toarray()) and np.array_equal(q2.uvar, qp.uvar)
+
+
+def test_reader_rows_ranges_bounds_and_sense():
+    qp = P.read_qps(MIXED_MPS)
+    assert qp.varnames == ["X1", "X2", "X3", "X4", "X5", "X6"]
+    assert qp.connames == ["EQ1", "LE1", "GE1", "EQR", "LER", "GER"]  # N rows dropped, order kept
+    # OBJSENSE MAX: everything of the objective negated; RHS on the objective row = -constant
+    assert np.array_equal(qp.c, -np.array([1.0, -2.0, 0, 0, 0.5, 0])) and qp.c0 == -7.0
+    A = np.zeros((6, 6))
+    A[0, 0], A[1, 0], A[2, 1], A[3, 1], A[4, 2], A[5, 2], A[0, 3], A[1, 5] = 1, 2, 1, 1, 1, -1, 3, 1
+    assert np.array_equal(qp.A.toarray(), A)
+    inf = np.inf
+    #                 EQ1  LE1   GE1  EQR(R<0)  LER(R=2)  GER(R=4)
+    assert np.array_equal(qp.lcon, [4.0, -inf, -1.0, -1.0, 3.0, 1.0])
+    assert np.array_equal(qp.ucon, [4.0, 10.0, inf, 2.0, 5.0, 5.0])
+    #                 X1   X2 (UP<0 -> lo=-inf)  X3    X4 (FX)  X5 (FR)  X6 (MI)
+    assert np.array_equal(qp.lvar, [0.0, -inf, -5.0, 2.5, -inf, -inf])
+    assert np.array_equal(qp.uvar, [4.0, -1.0, inf, 2.5, inf, inf])
+    with pytest.raises(ValueError):
+        P.read_qps("NAME X\nFOO\n")
+
+
+def test_ruiz_scaling_equilibrates_and_preserves_the_optimum():
+    qp0 = Q.random_qp(5, 30, 14)
+    qp0.A[:, 11] = 0.0  # an empty column
+    rng = np.random.default_rng(1)
+    dr = 10.0 ** rng.uniform(-3, 3, 14)
+    bad = sp.diags(dr) @ sp.csr_matrix(qp0.A)  # badly scaled rows (bounds scaled with them)
+    qp = P.HostQP(qp0.c0, qp0.q, sp.csr_matrix(qp0.H), bad, qp0.lvar, qp0.uvar, qp0.lcon * dr, qp0.ucon * dr)
+    qs, Dr, Dc = P.ruiz_scale(qp)
+    As = abs(qs.A)
+    rmax, cmax = As.max(axis=1).toarray().ravel(), As.max(axis=0).toarray().ravel()
+    assert np.max(np.abs(rmax[rmax > 0] - 1.0)) < 1e-6 and np.max(np.abs(cmax[cmax > 0] - 1.0)) < 1e-6
+    assert np.all(Dc[cmax == 0] == 1.0)  # empty columns keep the factor 1
+    # the transformation of scripts/common.jl:68-94
+    assert np.allclose(qs.A.toarray(), bad.toarray() / np.outer(Dr, Dc)) and np.allclose(qs.c, qp.c / Dc)
+    assert np.allclose(qs.H.toarray(), qp.H.toarray() / np.outer(Dc, Dc))
+    assert np.allclose(qs.uvar, qp.uvar * Dc) and np.allclose(qs.ucon, qp.ucon / Dr)
+    r, rs = solve(qp, max_iter=500), solve(qs, max_iter=500)
+    assert r["status"] == rs["status"] == mpc.SOLVE_SUCCEEDED
+    assert abs(r["objective"] - rs["objective"]) <= 1e-6 * max(1.0, abs(r["objective"]))
+    assert np.max(np.abs(rs["solution"] / Dc - r["solution"])) < 1e-5
+
+
+def test_standard_form_structure_and_equivalence():
+    """scripts/common.jl:109-288: counts, blocks and bounds of the reformulation; same optimum."""
+    qp = P.read_qps(MIXED_MPS)
+    qp.lvar[4] = -3.0  # X5: lower bound only
+    qp.uvar[5] = 6.0   # X6: upper bound only
+    sf = P.standard_form(qp)
+    n, m = 6, 6
+    ineq = [1, 2, 3, 4, 5]            # rows with lcon < ucon (EQR became a range through RANGES)
+    rng_x = [0]                       # X1 is the only variable with two finite, different bounds
+    rng_s = [k for k, i in enumerate(ineq) if np.isfinite(qp.lcon[i]) and np.isfinite(qp.ucon[i])]  # EQR, LER, GER
+    ns, nw = len(ineq), len(rng_x) + len(rng_s)
+    assert (sf.nvar, sf.ncon) == (n + ns + nw, m + nw) and sf.nnzj == qp.nnzj + ns + 2 * nw
+    A = sf.A.toarray()
+    assert np.array_equal(A[:m, :n], qp.A.toarray())
+    for k, i in enumerate(ineq):  # A x - s = 0
+        assert A[i, n + k] == -1.0 and sf.lcon[i] == sf.ucon[i] == 0.0
+    assert sf.lcon[0] == sf.ucon[0] == 4.0  # equality row kept
+    for k, j in enumerate(rng_x + [n + k for k in rng_s]):  # x + w = xu
+        row = A[m + k]
+        assert row[j] == 1.0 and row[n + ns + k] == 1.0 and np.count_nonzero(row) == 2
+        assert sf.lcon[m + k] == sf.ucon[m + k] == (qp.uvar[j] if j < n else qp.ucon[ineq[j - n]])
+        assert sf.uvar[j] == np.inf and sf.lvar[n + ns + k] == 0.0 and sf.uvar[n + ns + k] == np.inf
+    assert sf.lvar[3] == sf.uvar[3] == 2.5  # fixed variable kept in the formulation
+    assert sf.uvar[5] == 6.0                # upper bound only: stays a bound
+    # equivalence on a problem without fixed variables (the oracle does not treat them)
+    qp2 = Q.random_qp(5, 12, 7, lp=False)
+    h = P.HostQP(qp2.c0, qp2.q, sp.csr_matrix(qp2.H), sp.csr_matrix(qp2.A), qp2.lvar, qp2.uvar, qp2.lcon, qp2.ucon)
+    a, b = solve(h), solve(P.standard_form(h))
+    assert a["status"] == b["status"] == mpc.SOLVE_SUCCEEDED
+    assert abs(a["objective"] - b["objective"]) <= 1e-6 * max(1.0, abs(a["objective"]))
+    assert np.max(np.abs(b["solution"][:12] - a["solution"])) < 1e-5
+
+
+def test_benchmark_row():
+    qp = P.read_qps(HS21_QPS)
+    row = P.benchmark_row(qp, dict(status=1, iter=7, objective=-99.96), 0.5, 0.25)
+    assert row == (2, 1, 2, 2, 1, 7, -99.96, 0.5, 0.25)
