@@ -252,6 +252,11 @@ int32_t madqp_kkt_create_sparse(madqp_ctx* ctx, int32_t mode, int64_t nx, int64_
                                 const int64_t* a_col, const double* a_val, const int64_t* at_ptr,
                                 const int64_t* at_col, const double* at_val, madqp_kkt** out);
 
+/* H = diag(hdiag) (nx entries, device, borrowed) for a KKT object created without a dense H, either mode:
+ * condensed K = diag(hdiag) + Sigma_x + A' Theta A; normal equations A (H + Sigma)^-1 A' -- the diagonal-H
+ * extension of the LP-only NormalKKTSystem (src/KKT/normalkkt.jl:45-48) that CONT-type QPs need. */
+int32_t madqp_kkt_set_hdiag(madqp_kkt* kkt, const double* hdiag);
+
 /* ----------------------------------------- multi-GPU factorisation pieces */
 /* One dense KKT over several GPUs, one process per GPU: block columns ("panels", starts and widths
  * multiples of 128, the last one may be short) are dealt round-robin to the ranks.  A rank assembles

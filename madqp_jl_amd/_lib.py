@@ -127,6 +127,7 @@ _SIGNATURES = {
     "madqp_kkt_eval": [vp, pstate, vp, vp, f64, pf64],
     "madqp_kkt_matrix": [vp, C.POINTER(vp), pi64],
     "madqp_kkt_create_sparse": [vp, i32, i64, i64, i64, pi64, vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
+    "madqp_kkt_set_hdiag": [vp, vp],
     "madqp_syrk_assemble_cols": [vp, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, i64, pi64],
     "madqp_kkt_build_cols": [vp, pstate, i64, pi64],
     "madqp_kkt_chol": [vp, C.POINTER(vp), pi64],

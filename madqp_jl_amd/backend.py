@@ -292,6 +292,9 @@ class HipBackend:
                                                   ptr(csr.t_col), ptr(t_val), C.byref(h)))
         return h
 
+    def kkt_set_hdiag(self, h, hdiag):
+        self._ck(self.lib.madqp_kkt_set_hdiag(h, ptr(hdiag)))
+
     def kkt_destroy(self, h):
         self.lib.madqp_kkt_destroy(h)
 

@@ -40,6 +40,8 @@ class BatchedMPCSolver:
         if not (same(self.lvar) and same(self.uvar) and same(self.lcon) and same(self.ucon)
                 and bool(((self.lcon == self.ucon) == (self.lcon[0] == self.ucon[0])).all())):
             raise ValueError("all problems of a batch must share the pattern of finite bounds and equality rows")
+        if any(q.H is not None and q.H.dim() != 2 for q in self.qps) or any(not torch.is_tensor(q.A) for q in self.qps):
+            raise ValueError("the batched driver takes dense H and dense A")
         if any((q.H is None) != (q0.H is None) for q in self.qps):
             raise ValueError("all problems of a batch must be QPs or all LPs")
         self.ind_ineq, self.ind_eq = ic["ind_ineq"], ic["ind_eq"]

@@ -130,9 +130,10 @@ int32_t madqp_gemv_impl(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t col
 // sparse.hip
 int32_t madqp_spmv_csr(madqp_ctx* ctx, int64_t rows, const int64_t* rowptr, const int64_t* col, const double* val,
                        double alpha, const double* x, double beta, double* y, int prof_cls);
+// rows of V as CSR (rowptr/col/val) and columns of V as CSR of V' (t_ptr/t_col/t_val)
 int32_t madqp_sparse_gram(madqp_ctx* ctx, int64_t n, const int64_t* rowptr, const int64_t* col, const double* val,
-                          const double* w, const double* base, int64_t ldbase, const double* dvec, double* C,
-                          int64_t ldc);
+                          const int64_t* t_ptr, const int64_t* t_col, const double* t_val, const double* w,
+                          const double* base, int64_t ldbase, const double* dvec, double* C, int64_t ldc);
 
 struct madqp_chol {
     madqp_ctx* ctx;

@@ -35,6 +35,8 @@ struct madqp_kkt {
     // sparse front end (either mode): CSR of A (m rows) and CSR of A' (nx rows); A == At == nullptr then
     const int64_t *a_ptr, *a_col, *at_ptr, *at_col;
     const double *a_val, *at_val;
+    const double* hdiag;  // diagonal Hessian (nx), instead of the dense H; borrowed
+    double* sg;           // Sigma + [hdiag; 0] (n), owned; the solves divide by it
     double *dn, *tn;  // normal mode: 1/Sigma (n) and an n-vector of scratch
     int64_t* d_ind_ineq;  // ns
     int64_t* d_slot;      // m: slack slot of a row, -1 for an equality row
@@ -86,6 +88,7 @@ extern "C" int32_t madqp_kkt_destroy(madqp_kkt* k) {
     if (k->theta) (void)hipFree(k->theta);
     if (k->t) (void)hipFree(k->t);
     if (k->u) (void)hipFree(k->u);
+    if (k->sg) (void)hipFree(k->sg);
     if (k->dn) (void)hipFree(k->dn);
     if (k->tn) (void)hipFree(k->tn);
     delete k;
@@ -188,6 +191,23 @@ extern "C" int32_t madqp_kkt_create_sparse(madqp_ctx* ctx, int32_t mode, int64_t
     return MADQP_OK;
 }
 
+// Diagonal Hessian H = diag(hdiag) (nx entries, device, borrowed) for a KKT object created without a dense
+// H: the condensed matrix becomes diag(hdiag) + Sigma_x + A' Theta A, the normal equations A (H + Sigma)^-1 A'
+// ("the alternative of row 6 applies verbatim with Sigma -> H + Sigma") -- the reference's
+// NormalKKTSystem is LP only (src/KKT/normalkkt.jl:45-48); this is the diagonal-H extension CONT-type QPs need.
+extern "C" int32_t madqp_kkt_set_hdiag(madqp_kkt* k, const double* hdiag) {
+    if (!k) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = k->ctx;
+    ARG_TRY(ctx, hdiag && !k->H);
+    if (!k->sg) {
+        const size_t nb = (size_t)std::max<int64_t>(k->nx + k->ns, 1) * sizeof(double);
+        hipError_t e = hipMalloc(&k->sg, nb);
+        if (e != hipSuccess) return madqp_fail(ctx, MADQP_ERR_ALLOC, "madqp_kkt_set_hdiag: %s", hipGetErrorString(e));
+    }
+    k->hdiag = hdiag;
+    return MADQP_OK;
+}
+
 extern "C" int32_t madqp_kkt_create_normal(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
                                            const int64_t* ind_ineq_host, const double* At,
                                            int64_t ldat, madqp_kkt** out) {
@@ -218,27 +238,30 @@ static int32_t kkt_build_impl(madqp_kkt* k, const madqp_state* st, int64_t nrang
         // (src/KKT/normalkkt.jl:166-180, src/utils.jl:266-298)
         {
             ProfScope ps(ctx, MADQP_PROF_VEC);
-            if (st->n) KLAUNCH(recip_kernel, st->n, st->n, st->pr_diag, k->dn);
+            if (k->hdiag && st->n) KLAUNCH(sigma_h_kernel, st->n, st->n, k->nx, st->pr_diag, k->hdiag, k->sg);
+            if (st->n) KLAUNCH(recip_kernel, st->n, st->n, k->hdiag ? k->sg : st->pr_diag, k->dn);
             if (k->m) KLAUNCH(slack_diag_kernel, k->m, k->m, k->nx, k->d_slot, k->dn, k->theta);
         }
         if (k->a_ptr) {  // V = A (rows = constraints), weights 1/Sigma over the variables
             ARG_TRY(ctx, ranges == nullptr);
-            return madqp_sparse_gram(ctx, k->m, k->a_ptr, k->a_col, k->a_val, k->dn, nullptr, 0, k->theta, k->K,
-                                     k->ldk);
+            return madqp_sparse_gram(ctx, k->m, k->a_ptr, k->a_col, k->a_val, k->at_ptr, k->at_col, k->at_val, k->dn,
+                                     nullptr, 0, k->theta, k->K, k->ldk);
         }
         return madqp_syrk_assemble_ranges(ctx, k->m, k->nx, k->At, k->ldat, k->dn, nullptr, 0, k->theta,
                                           k->K, k->ldk, nranges, ranges);
     }
-    if (k->m) {
+    {
         ProfScope ps(ctx, MADQP_PROF_VEC);
-        KLAUNCH(theta_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, k->theta);
+        if (k->m) KLAUNCH(theta_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, k->theta);
+        if (k->hdiag && st->n) KLAUNCH(sigma_h_kernel, st->n, st->n, k->nx, st->pr_diag, k->hdiag, k->sg);
     }
+    const double* dvec = k->hdiag ? k->sg : st->pr_diag;  // diagonal of H + Sigma_x
     if (k->a_ptr) {  // V = A' (rows = variables), weights Theta over the constraints
         ARG_TRY(ctx, ranges == nullptr);
-        return madqp_sparse_gram(ctx, k->nx, k->at_ptr, k->at_col, k->at_val, k->theta, k->H, k->ldh, st->pr_diag,
-                                 k->K, k->ldk);
+        return madqp_sparse_gram(ctx, k->nx, k->at_ptr, k->at_col, k->at_val, k->a_ptr, k->a_col, k->a_val, k->theta,
+                                 k->H, k->ldh, dvec, k->K, k->ldk);
     }
-    return madqp_syrk_assemble_ranges(ctx, k->nx, k->m, k->A, k->lda, k->theta, k->H, k->ldh, st->pr_diag,
+    return madqp_syrk_assemble_ranges(ctx, k->nx, k->m, k->A, k->lda, k->theta, k->H, k->ldh, dvec,
                                       k->K, k->ldk, nranges, ranges);
 }
 
@@ -280,7 +303,7 @@ extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* 
     if (k->mode == KKT_NORMAL) {  // src/KKT/normalkkt.jl:185-201
         {
             ProfScope ps(ctx, MADQP_PROF_VEC);
-            if (st->n) KLAUNCH(div_kernel, st->n, st->n, wx, st->pr_diag, k->tn);  // r1 = Sigma^-1 wx
+            if (st->n) KLAUNCH(div_kernel, st->n, st->n, wx, k->hdiag ? k->sg : st->pr_diag, k->tn);  // r1 = (H + Sigma)^-1 wx
         }
         if ((r = apply_A(k, 1.0, k->tn, 0.0, k->u))) return r;
         if (k->m) {
@@ -292,7 +315,7 @@ extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* 
         {
             ProfScope ps(ctx, MADQP_PROF_VEC);
             if (k->ns) KLAUNCH(jt_slack_kernel, k->ns, k->ns, k->d_ind_ineq, wy, k->tn + k->nx, 1.0, 0.0);
-            if (st->n) KLAUNCH(normal_back_kernel, st->n, st->n, k->tn, st->pr_diag, wx);
+            if (st->n) KLAUNCH(normal_back_kernel, st->n, st->n, k->tn, k->hdiag ? k->sg : st->pr_diag, wx);
         }
         return madqp_finish_aug_solve(ctx, st, w);
     }
@@ -340,6 +363,10 @@ extern "C" int32_t madqp_kkt_mul(madqp_kkt* k, const madqp_state* st, double* w,
     if (k->H && nx)
         if ((r = madqp_gemv_impl(ctx, 0, nx, nx, alpha, k->H, k->ldh, v, 1.0, w, MADQP_PROF_GEMV)))
             return r;
+    if (k->hdiag && nx) {
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        KLAUNCH(hdiag_axpy_kernel, nx, nx, alpha, k->hdiag, v, w);
+    }
     if (k->ns) {
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(jt_slack_kernel, k->ns, k->ns, k->d_ind_ineq, v + n, w + nx, alpha, beta);
@@ -363,13 +390,17 @@ extern "C" int32_t madqp_kkt_eval(madqp_kkt* k, const madqp_state* st, const dou
     if (k->H && nx)
         if ((r = madqp_gemv_impl(ctx, 0, nx, nx, 1.0, k->H, k->ldh, st->x, 0.0, st->f, MADQP_PROF_GEMV)))
             return r;
+    if (k->hdiag && nx) {
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        KLAUNCH(hdiag_mul_kernel, nx, nx, k->hdiag, st->x, st->f);
+    }
     double sums[2] = {0.0, 0.0};
     if (n) {
         const int nb = grid_for(n);
         {
             ProfScope ps(ctx, MADQP_PROF_VEC);
             hipLaunchKernelGGL(eval_grad_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, n, nx,
-                               (k->H && nx) ? 1 : 0, q, st->x, st->f, ctx->d_part);
+                               ((k->H || k->hdiag) && nx) ? 1 : 0, q, st->x, st->f, ctx->d_part);
             LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(sum2_final_kernel, dim3(1), dim3(TPB), 0, ctx->stream, ctx->d_part, nb,
                                ctx->d_res);

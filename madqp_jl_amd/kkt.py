@@ -147,6 +147,7 @@ class _SparseMixin:
     reference: src/utils.jl:148-298, src/KKT/normalkkt.jl:51-101)."""
 
     def _init_sparse(self, backend, st, nx, ind_ineq, H, csr, mode):
+        """``H``: None, a dense (nx, nx) tensor (condensed mode) or a 1-D tensor = diagonal of H (either mode)."""
         self.be, self.st = backend, st
         self.nx, self.m = int(nx), st.m
         self.ind_ineq = [int(i) for i in ind_ineq]
@@ -154,21 +155,29 @@ class _SparseMixin:
         assert st.n == self.nx + self.ns and (csr.m, csr.n) == (self.m, self.nx)
         self.H, self.A, self.csr = H, None, csr
         self._t_val = csr.t_val  # values of A' in CSR order, borrowed by the library
-        self._h = backend.kkt_create_sparse(mode, self.nx, self.m, self.ind_ineq, H, max(self.nx, 1), csr,
-                                            self._t_val)
+        diag = H is not None and H.dim() == 1
+        self._h = backend.kkt_create_sparse(mode, self.nx, self.m, self.ind_ineq, None if diag else H,
+                                            max(self.nx, 1), csr, self._t_val)
+        if diag:
+            assert H.is_contiguous() and H.numel() == self.nx
+            backend.kkt_set_hdiag(self._h, H)
         self.linear_solver = HIPCholeskySolver(backend, self._h)
         self.n_factorizations = 0
 
 
 class HIPSparseCondensedKKTSystem(_SparseMixin, HIPCondensedKKTSystem):
     def __init__(self, backend, st, nx, ind_ineq, H, csr):
-        if H is not None:
+        if H is not None and H.dim() == 2:
             assert H.is_contiguous() and H.shape == (nx, nx)
         self._init_sparse(backend, st, nx, ind_ineq, H, csr, 0)
 
 
 class HIPSparseNormalKKTSystem(_SparseMixin, HIPNormalKKTSystem):
+    """Normal equations A (H + Sigma)^-1 A' with H = 0 (the reference's LP-only NormalKKTSystem) or H diagonal
+    (1-D tensor; SURVEY.md 8a-note -- what CONT-type QPs need)."""
+
     def __init__(self, backend, st, nx, ind_ineq, H, csr):
-        if H is not None:
-            raise ValueError("The KKT system NormalKKTSystem supports only linear programs.")  # normalkkt.jl:45-48
-        self._init_sparse(backend, st, nx, ind_ineq, None, csr, 1)
+        if H is not None and H.dim() != 1:
+            raise ValueError("The KKT system NormalKKTSystem supports only linear programs "
+                             "(or a diagonal Hessian given as a vector).")  # normalkkt.jl:45-48
+        self._init_sparse(backend, st, nx, ind_ineq, H, csr, 1)

@@ -318,7 +318,13 @@ def to_device(qp: HostQP, backend, sparse: bool = True):
 
     dev = backend.device
     f = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
-    H = None if qp.H.nnz == 0 else f(qp.H.toarray())
+    Hc = qp.H.tocoo()
+    if qp.H.nnz == 0:
+        H = None
+    elif sparse and np.all(Hc.row == Hc.col):
+        H = f(qp.H.diagonal())  # diagonal Hessian: kept as a vector (madqp_kkt_set_hdiag)
+    else:
+        H = f(qp.H.toarray())
     Ac = qp.A.tocoo()
     A = DeviceCSR(dev, qp.ncon, qp.nvar, Ac.row, Ac.col, Ac.data) if sparse else f(qp.A.toarray())
     return DeviceQP(H, f(qp.c), A, f(qp.lvar), f(qp.uvar), f(qp.lcon), f(qp.ucon), f(qp.x0), qp.c0, f(qp.y0), qp.name)
@@ -328,3 +334,40 @@ def benchmark_row(qp: HostQP, result: dict, total_time: float, linear_solver_tim
     """The nine numbers the reference's scripts record per instance (scripts/benchmarks_cpu.jl:47-55)."""
     return (qp.nvar, qp.ncon, qp.nnzj, qp.nnzh, int(result["status"]), int(result["iter"]),
             float(result["objective"]), float(total_time), float(linear_solver_time))
+
+
+# ------------------------------------------------------------------------ a CONT-type instance generator
+def boundary_control_qp(N: int, alpha: float = 0.01, ymax: float = 0.8) -> HostQP:
+    """Elliptic boundary-control QP on an N x N grid, the problem class of the Maros-Meszaros CONT-xxx
+    instances (BASELINE configs[2] names CONT-300; its data file is not available offline, so this is a
+    stand-in of the same shape, not that instance):
+
+        min  h^2/2 sum (y_ij - yd_ij)^2 + alpha h/2 sum u_k^2
+        s.t. 4 y_ij - y_(i-1)j - y_(i+1)j - y_i(j-1) - y_i(j+1) = 0   (5-point Laplacian; a neighbour outside
+             0 <= y <= ymax,  0 <= u <= 1                              the grid is a boundary control u_k)
+
+    n = N^2 + 4N variables [y; u_left; u_right; u_bottom; u_top], m = N^2 equality rows with <= 5 entries,
+    diagonal Hessian.  N = 300: n = 91 200, m = 90 000 (CONT-300: 90 597 x 90 298)."""
+    h = 1.0 / (N + 1)
+    idx = lambda i, j: i * N + j
+    ul, ur, ub, ut = N * N, N * N + N, N * N + 2 * N, N * N + 3 * N
+    rows, cols, vals = [], [], []
+    for i in range(N):
+        for j in range(N):
+            r = idx(i, j)
+            rows.append(r); cols.append(r); vals.append(4.0)
+            for (ii, jj, ctrl) in ((i - 1, j, ul + j), (i + 1, j, ur + j), (i, j - 1, ub + i), (i, j + 1, ut + i)):
+                inside = 0 <= ii < N and 0 <= jj < N
+                rows.append(r)
+                cols.append(idx(ii, jj) if inside else ctrl)
+                vals.append(-1.0)
+    n, m = N * N + 4 * N, N * N
+    g = (np.arange(N) + 1) * h
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    yd = (1.0 + 2.0 * (X * (X - 1.0) + Y * (Y - 1.0))).ravel()
+    hd = np.concatenate([np.full(N * N, h * h), np.full(4 * N, alpha * h)])
+    c = np.concatenate([-h * h * yd, np.zeros(4 * N)])
+    lvar = np.zeros(n)
+    uvar = np.concatenate([np.full(N * N, ymax), np.ones(4 * N)])
+    return HostQP(0.5 * h * h * float(yd @ yd), c, sp.diags(hd).tocsr(), sp.csr_matrix((vals, (rows, cols)), shape=(m, n)),
+                  lvar, uvar, np.zeros(m), np.zeros(m), name=f"boundary-control-{N}")

@@ -98,7 +98,10 @@ class MPCSolver:
         reg = self.opt.regularization
         if self.opt.kkt_system not in ("condensed", "normal"):
             raise ValueError(f"unknown kkt_system {self.opt.kkt_system!r}")
-        if self.opt.kkt_system == "normal" and qp.H is not None:
+        diag_h = qp.H is not None and qp.H.dim() == 1  # H = diag(vector): sparse front end only
+        if diag_h and not isinstance(qp.A, DeviceCSR):
+            raise ValueError("a diagonal Hessian (1-D tensor) needs the sparse front end (A as DeviceCSR)")
+        if self.opt.kkt_system == "normal" and qp.H is not None and not diag_h:
             raise ValueError("The KKT system NormalKKTSystem supports only linear programs.")
         if self.opt.kkt_system == "condensed" and len(self.ind_eq) and (
                 isinstance(reg, NoRegularization) or reg.delta_d >= 0.0):
@@ -311,7 +314,10 @@ class MPCSolver:
             g = st.f[:nx]  # scratch: gradient at the pushed start
             g.copy_(qp.q)
             if qp.H is not None and nx:
-                be.gemv(0, nx, nx, 1.0, qp.H, nx, st.x, 1.0, g)
+                if qp.H.dim() == 1:
+                    g.add_(qp.H * st.x[:nx])
+                else:
+                    be.gemv(0, nx, nx, 1.0, qp.H, nx, st.x, 1.0, g)
             gmax = be.norm_inf(g) if nx else 0.0
             self.obj_scale = min(1.0, 100.0 / gmax) if gmax > 0 else 1.0
             self.con_scale = con_scale

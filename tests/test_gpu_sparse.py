@@ -141,3 +141,35 @@ def test_instance_file_to_gpu_pipeline(hip):
     assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
     assert abs(r["objective"] - ref["objective"]) <= 1e-6 * max(1.0, abs(ref["objective"]))
     assert np.max(np.abs(r["solution"][:40] - ref["solution"])) < 1e-5
+
+
+@pytest.mark.parametrize("N,ksys", [(12, "normal"), (25, "normal"), (12, "condensed")])
+def test_boundary_control_qp_diagonal_hessian(hip, N, ksys):
+    """CONT-type QP (BASELINE configs[2] stand-in): sparse equality rows, diagonal Hessian kept as a vector.
+    Normal equations A (H + Sigma)^-1 A' (the diagonal-H extension of the LP-only NormalKKTSystem) against the
+    oracle's K2 system on the densified problem -- the equality the reference asserts for LPs
+    (test/runtests.jl:165-180); condensed form with Theta = -1/delta_d on the equality rows."""
+    from madqp_jl_amd import preprocess as P
+
+    h = P.boundary_control_qp(N)
+    dq = P.to_device(h, hip)
+    assert dq.H.dim() == 1 and isinstance(dq.A, M.DeviceCSR)
+    dense = Q.DenseQP(H=h.H.toarray(), q=h.c, A=h.A.toarray(), lvar=h.lvar, uvar=h.uvar, lcon=h.lcon, ucon=h.ucon,
+                      x0=h.x0, c0=h.c0)
+    if ksys == "normal":
+        reg, oreg = M.FixedRegularization(1e-8, 0.0), mpc.FixedRegularization(1e-8, 0.0)
+        ref = mpc.solve(dense, kkt_system="K2", regularization=oreg)
+    else:
+        reg, oreg = REG, mpc.FixedRegularization(1e-8, -1e-8)
+        ref = mpc.solve(dense, kkt_system="condensed", regularization=oreg)
+    for driver in ("python", "native"):
+        s = M.MPCSolver(dq, hip, kkt_system=ksys, regularization=reg, driver=driver)
+        r = s.solve()
+        s.close()
+        assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"], (r["iter"], ref["iter"])
+        tol = 1e-9 if ksys == "normal" else 1e-6  # condensed: Theta = 1e8 on every row
+        assert abs(r["objective"] - ref["objective"]) <= tol * max(1.0, abs(ref["objective"]))
+        assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e3 * tol
+        for t, g in zip(r["trace"], ref["trace"]):
+            for key in ("alpha_p", "alpha_d", "mu"):
+                assert close(t[key], g[key], 1e-6 if ksys == "normal" else 1e-4), (t["k"], key, t[key], g[key])

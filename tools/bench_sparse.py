@@ -20,12 +20,40 @@ def main():
     p.add_argument("--per-row", type=int, default=8)
     p.add_argument("--kkt", choices=("normal", "condensed"), default="normal")
     p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--cont", type=int, default=0, help="N > 0: the CONT-type boundary-control QP on an N x N grid "
+                   "(preprocess.boundary_control_qp; N = 300 has the shape of Maros-Meszaros CONT-300), solved to the end")
     a = p.parse_args()
     import torch
 
     import madqp_jl_amd as M
 
     be = M.HipBackend(0)
+    if a.cont:
+        from madqp_jl_amd import preprocess as P
+
+        t0 = time.perf_counter()
+        h = P.boundary_control_qp(a.cont)
+        qp = P.to_device(h, be)
+        t_gen = time.perf_counter() - t0
+        s = M.MPCSolver(qp, be, kkt_system="normal", regularization=M.FixedRegularization(1e-8, 0.0), driver="native",
+                        max_iter=100)
+        be.prof_enable(M._lib.PROF_CLASSES)
+        be.prof_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = s.solve()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = be.prof_get()
+        nf = max(r["n_factorizations"], 1)
+        print(json.dumps({"workload": f"boundary-control QP N={a.cont}: nx={h.nvar} m={h.ncon} nnz={h.nnzj}, diagonal H, "
+                                      "normal equations (m x m dense)", "status": r["status"], "iterations": r["iter"],
+                          "objective": r["objective"], "solve_seconds": dt, "generate_seconds": t_gen,
+                          "factorizations": r["n_factorizations"],
+                          "ms_per_factorization": {c: round(v[0] / nf, 2) for c, v in prof.items() if v[1]},
+                          "last": r["trace"][-1]}))
+        s.close()
+        return
     rng = np.random.default_rng(7)
     m, n, k = a.ncon, a.nx, a.per_row
     rows = np.repeat(np.arange(m), k + 1)
