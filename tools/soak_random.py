@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""One-off soak: many random bound patterns / shapes through the per-problem drivers, the sparse front end and
+the batched engine, each against the CPU oracle.  python tools/soak_random.py --count 150"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--count", type=int, default=100)
+    p.add_argument("--seed0", type=int, default=1000)
+    a = p.parse_args()
+    import madqp_jl_amd as M
+    from oracle import mpc
+    from oracle import qp as Q
+
+    be = M.HipBackend(0)
+    REG, OREG = M.FixedRegularization(1e-8, -1e-8), mpc.FixedRegularization(1e-8, -1e-8)
+    rng = np.random.default_rng(a.seed0)
+    bad = 0
+    for t in range(a.count):
+        seed = a.seed0 + t
+        n = int(rng.integers(1, 260))
+        m = int(rng.integers(0, max(1, n)))
+        lp = bool(rng.integers(0, 4) == 0)
+        qp = Q.random_qp(seed, n, m, lp)
+        ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG)
+        dq = M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
+        outs = {}
+        for name, mk in (("python", lambda: M.MPCSolver(dq, be, regularization=REG)),
+                         ("native", lambda: M.MPCSolver(dq, be, regularization=REG, driver="native")),
+                         ("batched", lambda: M.BatchedMPCSolver([dq], be, regularization=REG))):
+            s = mk()
+            r = s.solve()
+            outs[name] = r[0] if name == "batched" else r
+            s.close()
+        for name, r in outs.items():
+            ok = (r["status"] == ref["status"] and (r["status"] != 1 or (
+                r["iter"] == ref["iter"] and abs(r["objective"] - ref["objective"]) <= 1e-7 * max(1, abs(ref["objective"]))
+                and np.max(np.abs(r["solution"] - ref["solution"]), initial=0) <= 1e-5)))
+            if not ok:
+                bad += 1
+                print("MISMATCH", seed, n, m, lp, name, r["status"], ref["status"], r["iter"], ref["iter"],
+                      r["objective"], ref["objective"], flush=True)
+        if (t + 1) % 25 == 0:
+            print(f"{t + 1} problems, {bad} mismatches", flush=True)
+    print(f"done: {a.count} problems, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
