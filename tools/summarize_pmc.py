@@ -97,7 +97,9 @@ for k in ("trsv_fwd_sweep_kernel", "trsv_bwd_sweep_kernel", "gemv_n_wave", "gemv
             e["algorithmic_GB_per_launch"] = round(4.0 * nx * nx / 1e9, 3)  # half of L, 8 B per entry
         rates[k] = e
 out["hbm_bound_kernels"] = rates
-out["config"] = dict(nx=nx, m=m, command=f"rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --nx {nx} --m {m}")
+bench_args = sys.argv[4] if len(sys.argv) > 4 else "(defaults: --steps 3 --warmup 1)"
+out["config"] = dict(nx=nx, m=m, command=f"rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-cpu-baseline {bench_args} "
+                                         f"[nx={nx}, m={m}]; one pass per counter group (tools/profile_bench.sh)")
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 for f in glob.glob(f"gpurun_out/prof_{tag}_stats/*/*_kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_bench50k_kernel_stats.csv")
