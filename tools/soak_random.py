@@ -15,6 +15,9 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--count", type=int, default=100)
     p.add_argument("--seed0", type=int, default=1000)
+    p.add_argument("--mode", choices=("drivers", "sparse"), default="drivers",
+                   help="drivers: python / native / batched on dense data; sparse: CSR front end, condensed and (LPs) "
+                        "normal equations, against the dense path's oracle")
     a = p.parse_args()
     import madqp_jl_amd as M
     from oracle import mpc
@@ -33,9 +36,25 @@ def main():
         ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG)
         dq = M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
         outs = {}
-        for name, mk in (("python", lambda: M.MPCSolver(dq, be, regularization=REG)),
-                         ("native", lambda: M.MPCSolver(dq, be, regularization=REG, driver="native")),
-                         ("batched", lambda: M.BatchedMPCSolver([dq], be, regularization=REG))):
+        if a.mode == "sparse":
+            if m == 0 or n < 2:
+                continue
+            keep = rng.random(qp.A.shape) < min(1.0, 6.0 / n)  # ~6 entries per row, feasibility kept by re-centring
+            keep[np.arange(m), rng.integers(0, n, m)] = True
+            xf = rng.uniform(-0.5, 0.5, n)
+            xf = np.clip(xf, np.where(np.isfinite(qp.lvar), qp.lvar + 0.1, -np.inf), np.where(np.isfinite(qp.uvar), qp.uvar - 0.1, np.inf))
+            old = qp.A @ xf
+            qp.A = np.where(keep, qp.A, 0.0)
+            shift = qp.A @ xf - old
+            qp.lcon, qp.ucon = qp.lcon + shift, qp.ucon + shift
+            ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG)
+            ds = M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0, sparse=True)
+            cands = [("sparse-condensed", lambda: M.MPCSolver(ds, be, regularization=REG, driver="native"))]
+        else:
+            cands = [("python", lambda: M.MPCSolver(dq, be, regularization=REG)),
+                     ("native", lambda: M.MPCSolver(dq, be, regularization=REG, driver="native")),
+                     ("batched", lambda: M.BatchedMPCSolver([dq], be, regularization=REG))]
+        for name, mk in cands:
             s = mk()
             r = s.solve()
             outs[name] = r[0] if name == "batched" else r
