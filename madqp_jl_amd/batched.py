@@ -35,7 +35,8 @@ class BatchedMPCSolver:
         st = lambda name: torch.stack([getattr(q, name) for q in self.qps]).contiguous()
         self.lvar, self.uvar, self.lcon, self.ucon = st("lvar"), st("uvar"), st("lcon"), st("ucon")
         host = lambda t: t.detach().cpu().numpy()
-        ic = get_index_constraints(host(self.lvar[0]), host(self.uvar[0]), host(self.lcon[0]), host(self.ucon[0]))
+        ic = get_index_constraints(host(self.lvar[0]), host(self.uvar[0]), host(self.lcon[0]), host(self.ucon[0]),
+                                   self.opt.fixed_variable_treatment or "relax_bound")
         same = lambda a: bool((torch.isfinite(a) == torch.isfinite(a[0])).all())
         if not (same(self.lvar) and same(self.uvar) and same(self.lcon) and same(self.ucon)
                 and bool(((self.lcon == self.ucon) == (self.lcon[0] == self.ucon[0])).all())):

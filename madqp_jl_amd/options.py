@@ -43,6 +43,11 @@ class IPMOptions:
         bound_relax_factor=1e-8, max_ncorr=0, mu_init=1e-1, mu_min=1e-11,
         tol_linear_solve=1e-8, check_residual=False, rethrow_error=False, print_level=0,
         kkt_system="condensed",  # "condensed" (HIPCondensedKKTSystem) or "normal" (HIPNormalKKTSystem, LP)
+        # MadNLP.RelaxBound ("relax_bound": a fixed variable keeps both bounds, relaxed by bound_relax_factor like any
+        # other) is what the reference selects for condensed KKT systems, MakeParameter otherwise (src/utils.jl:81);
+        # elimination of fixed variables is not implemented: None = "relax_bound" for the condensed system, "error"
+        # for the normal equations
+        fixed_variable_treatment=None,
         distributed=False,  # True: assembly + Cholesky shared by the ranks of torch.distributed (dist.py)
         panel_width=None,  # block-column width of the distributed factorisation (multiple of 128)
         driver="python",  # "python": this package drives each kernel; "native": one C call per iteration

@@ -34,15 +34,17 @@ class SolveException(Exception):
     """MadNLP.SolveException (src/linear_solver.jl:41-43)."""
 
 
-def get_index_constraints(lvar, uvar, lcon, ucon):
-    """MadNLP.get_index_constraints as called at src/structure.jl:95-102 (host, numpy);
-    EnforceEquality / no fixed variables."""
+def get_index_constraints(lvar, uvar, lcon, ucon, fixed_variable_treatment="error"):
+    """MadNLP.get_index_constraints as called at src/structure.jl:95-102 (host, numpy); EnforceEquality.
+    Fixed variables (lvar == uvar): "relax_bound" = MadNLP.RelaxBound (they stay variables with both bounds, which
+    initialize relaxes by bound_relax_factor), "error" = refuse (MakeParameter, their elimination, is not built)."""
     ind_eq = np.flatnonzero(lcon == ucon)
     ind_ineq = np.flatnonzero(lcon != ucon)
     xl = np.concatenate([lvar, lcon[ind_ineq]])
     xu = np.concatenate([uvar, ucon[ind_ineq]])
-    if np.any(xl == xu):
-        raise NotImplementedError("fixed variables are not supported on the HIP path yet")
+    if np.any(xl == xu) and fixed_variable_treatment != "relax_bound":
+        raise NotImplementedError("fixed variables: pass fixed_variable_treatment='relax_bound' "
+                                  "(MakeParameter is not implemented)")
     return dict(ind_eq=ind_eq, ind_ineq=ind_ineq, ind_lb=np.flatnonzero(xl != -np.inf),
                 ind_ub=np.flatnonzero(xu != np.inf))
 
@@ -89,7 +91,8 @@ class MPCSolver:
         self.qp, self.be = qp, backend
         self.opt = IPMOptions(**opts)
         host = lambda t: t.detach().cpu().numpy()
-        ic = get_index_constraints(host(qp.lvar), host(qp.uvar), host(qp.lcon), host(qp.ucon))
+        fvt = self.opt.fixed_variable_treatment or ("relax_bound" if self.opt.kkt_system == "condensed" else "error")
+        ic = get_index_constraints(host(qp.lvar), host(qp.uvar), host(qp.lcon), host(qp.ucon), fvt)
         self.ind_ineq, self.ind_eq = ic["ind_ineq"], ic["ind_eq"]
         self.nx, self.ns = qp.nvar, len(self.ind_ineq)
         self.n, self.m = self.nx + self.ns, qp.ncon

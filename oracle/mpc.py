@@ -88,6 +88,7 @@ class IPMOptions:
         self.tol_linear_solve = 1e-8
         self.check_residual = False
         self.kkt_system = "K2"
+        self.fixed_variable_treatment = "error"  # or "relax_bound" (MadNLP.RelaxBound)
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError(f"unknown option {k}")
@@ -97,17 +98,19 @@ class IPMOptions:
 # --------------------------------------------------------------------------
 # MadNLP-recall pieces
 # --------------------------------------------------------------------------
-def get_index_constraints(lvar, uvar, lcon, ucon):
+def get_index_constraints(lvar, uvar, lcon, ucon, fixed_variable_treatment="error"):
     """MadNLP.get_index_constraints (called src/structure.jl:95-102).
 
-    EnforceEquality / MakeParameter defaults (src/utils.jl:81-82); fixed
-    variables are not supported by the oracle.
+    EnforceEquality (src/utils.jl:82).  Fixed variables: "relax_bound" = MadNLP.RelaxBound (MadNLP-recall: they
+    stay variables with both bounds, relaxed by bound_relax_factor in initialize like every bound -- the
+    treatment src/utils.jl:81 selects for condensed KKT systems); MakeParameter (elimination) is out of the
+    oracle's scope.
     """
     ind_eq = np.flatnonzero(lcon == ucon)
     ind_ineq = np.flatnonzero(lcon != ucon)
     xl = np.concatenate([lvar, lcon[ind_ineq]])
     xu = np.concatenate([uvar, ucon[ind_ineq]])
-    if np.any(xl == xu):
+    if np.any(xl == xu) and fixed_variable_treatment != "relax_bound":
         raise NotImplementedError("fixed variables (MakeParameter) are out of the oracle's scope")
     ind_lb = np.flatnonzero(xl != -np.inf)
     ind_ub = np.flatnonzero(xu != np.inf)
@@ -355,7 +358,7 @@ class MPCSolver:
     def __init__(self, qp: DenseQP, **opts):
         self.qp = qp
         self.opt = IPMOptions(**opts)
-        ic = get_index_constraints(qp.lvar, qp.uvar, qp.lcon, qp.ucon)
+        ic = get_index_constraints(qp.lvar, qp.uvar, qp.lcon, qp.ucon, self.opt.fixed_variable_treatment)
         self.ind_ineq, self.ind_eq = ic["ind_ineq"], ic["ind_eq"]
         self.ind_lb, self.ind_ub = ic["ind_lb"], ic["ind_ub"]
         self.nx, self.ns = qp.nvar, len(self.ind_ineq)

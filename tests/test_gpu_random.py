@@ -59,3 +59,35 @@ def test_random_patterns_batched(hip):
     b.close()
     for i, (qp, r) in enumerate(zip(qps, res)):
         same(r, mpc.solve(qp, kkt_system="condensed", regularization=OREG), f"batch member {i}")
+
+
+def test_fixed_variables_relax_bound(hip):
+    """Fixed variables (FX bounds of instance files): RelaxBound is the default of the condensed system, as in the
+    reference (src/utils.jl:81); every driver follows the oracle; the normal equations refuse without the option."""
+    qp = Q.random_qp(5, 40, 22)
+    fixed = [3, 8, 31]
+    qp.lvar[fixed] = qp.uvar[fixed] = np.array([0.25, -0.4, 0.0])
+    ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG, fixed_variable_treatment="relax_bound")
+    for mk in (lambda: M.MPCSolver(to_device(qp, hip), hip, regularization=REG),
+               lambda: M.MPCSolver(to_device(qp, hip), hip, regularization=REG, driver="native"),
+               lambda: M.MPCSolver(to_device(qp, hip, sparse=True), hip, regularization=REG)):
+        s = mk()
+        r = s.solve()
+        s.close()
+        same(r, ref, "fixed variables")
+        assert np.allclose(r["solution"][fixed], [0.25, -0.4, 0.0], atol=1e-7)
+    b = M.BatchedMPCSolver([to_device(qp, hip)], hip, regularization=REG)
+    same(b.solve()[0], ref, "fixed variables, batched")
+    b.close()
+    with pytest.raises(NotImplementedError):
+        M.MPCSolver(to_device(qp, hip), hip, regularization=REG, fixed_variable_treatment="error")
+    lp = Q.random_qp(6, 30, 12, lp=True)
+    lp.lvar[2] = lp.uvar[2] = 0.1
+    with pytest.raises(NotImplementedError):  # NormalKKTSystem would use MakeParameter (not built)
+        M.MPCSolver(to_device(lp, hip), hip, kkt_system="normal", regularization=M.FixedRegularization(1e-8, 0.0))
+    s = M.MPCSolver(to_device(lp, hip), hip, kkt_system="normal", regularization=M.FixedRegularization(1e-8, 0.0),
+                    fixed_variable_treatment="relax_bound")
+    r = s.solve()
+    s.close()
+    same(r, mpc.solve(lp, kkt_system="normal", regularization=mpc.FixedRegularization(1e-8, 0.0),
+                      fixed_variable_treatment="relax_bound"), "fixed variable, normal equations")

@@ -209,3 +209,25 @@ def test_solutions_carry_an_optimality_certificate(make):
     # the certified point
     assert abs(res.fun - r["objective"]) <= 1e-3 * max(1.0, abs(r["objective"]))
     assert res.fun >= r["objective"] - 1e-6 * max(1.0, abs(r["objective"]))
+
+
+def test_fixed_variables_relax_bound_equals_elimination():
+    """MadNLP.RelaxBound (what src/utils.jl:81 selects for condensed KKT systems): a fixed variable keeps both
+    bounds, relaxed by bound_relax_factor; the optimum equals the one of the problem with the variable
+    eliminated, to the size of the relaxation.  Without the option the oracle refuses (MakeParameter is not built)."""
+    qp = Q.random_qp(5, 12, 7)
+    fixed, vals = [3, 8], np.array([0.25, -0.4])
+    qp.lvar[fixed] = qp.uvar[fixed] = vals
+    with pytest.raises(NotImplementedError):
+        mpc.solve(qp, kkt_system="condensed", regularization=REG())
+    keep = [i for i in range(12) if i not in fixed]
+    red = Q.DenseQP(H=qp.H[np.ix_(keep, keep)], q=qp.q[keep] + qp.H[np.ix_(keep, fixed)] @ vals, A=qp.A[:, keep],
+                    lvar=qp.lvar[keep], uvar=qp.uvar[keep], lcon=qp.lcon - qp.A[:, fixed] @ vals,
+                    ucon=qp.ucon - qp.A[:, fixed] @ vals, x0=np.zeros(10),
+                    c0=qp.c0 + qp.q[fixed] @ vals + 0.5 * vals @ qp.H[np.ix_(fixed, fixed)] @ vals)
+    ref = mpc.solve(red, kkt_system="condensed", regularization=REG())
+    for kkt in ("K2", "condensed"):
+        r = mpc.solve(qp, kkt_system=kkt, regularization=REG(), fixed_variable_treatment="relax_bound")
+        assert r["status"] == ref["status"] == mpc.SOLVE_SUCCEEDED
+        assert abs(r["objective"] - ref["objective"]) < 1e-6 and np.allclose(r["solution"][fixed], vals, atol=1e-7)
+        assert np.max(np.abs(r["solution"][keep] - ref["solution"])) < 1e-5
