@@ -460,6 +460,9 @@ class MPCSolver:
             self.iteration_body()
 
     def solve(self):  # :347-403
+        import time
+
+        t0 = time.perf_counter()
         try:
             self.initialize()
             self.status = self.mpc()
@@ -471,6 +474,8 @@ class MPCSolver:
             self.status = INTERNAL_ERROR
             if self.opt.rethrow_error:
                 raise
+        finally:
+            self.total_time = time.perf_counter() - t0  # counters.total_time (scripts/benchmarks_cpu.jl:54)
         return self.result()
 
     def close(self):
@@ -491,4 +496,21 @@ class MPCSolver:
             multipliers_L=h(st.zl[:nx]) / self.obj_scale,
             multipliers_U=h(st.zu[:nx]) / self.obj_scale,
             trace=self.trace, n_factorizations=self.kkt.n_factorizations if self.kkt else 0,
+            total_time=getattr(self, "total_time", 0.0),
         )
+
+
+def madipm(qp: DeviceQP, backend=None, **opts):
+    """``MadIPM.madipm(qp; kwargs...)`` (src/solver.jl:405-409): construct, solve, release; returns the result
+    dictionary of :meth:`MPCSolver.result`."""
+    from .backend import HipBackend
+
+    own = backend is None
+    be = HipBackend(qp.q.device.index or 0) if own else backend
+    solver = MPCSolver(qp, be, **opts)
+    try:
+        return solver.solve()
+    finally:
+        solver.close()
+        if own:
+            be.close()
