@@ -16,10 +16,10 @@ from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, Fi
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
 from .qp import DeviceCSR, DeviceQP, stream_key
 from .solver import (ERROR_IN_STEP_COMPUTATION, MAXIMUM_ITERATIONS_EXCEEDED, SOLVE_SUCCEEDED,
-                     MPCSolver, SolveException, madipm)
+                     MPCSolver, SolveException, solve)
 
 __all__ = [
-    "HipBackend", "State", "shard", "solve_batch", "BatchedMPCSolver", "madipm", "HIPCholeskySolver", "HIPCondensedKKTSystem", "HIPNormalKKTSystem", "HIPSparseCondensedKKTSystem", "HIPSparseNormalKKTSystem", "MPCSolver", "DeviceQP",
+    "HipBackend", "State", "shard", "solve_batch", "BatchedMPCSolver", "solve", "HIPCholeskySolver", "HIPCondensedKKTSystem", "HIPNormalKKTSystem", "HIPSparseCondensedKKTSystem", "HIPSparseNormalKKTSystem", "MPCSolver", "DeviceQP",
     "DeviceCSR",
     "IPMOptions", "AdaptiveStep", "ConservativeStep", "MehrotraAdaptiveStep", "NoRegularization",
     "FixedRegularization", "AdaptiveRegularization", "MadQPError", "SolveException", "load_cdll",

@@ -500,8 +500,9 @@ class MPCSolver:
         )
 
 
-def madipm(qp: DeviceQP, backend=None, **opts):
-    """``MadIPM.madipm(qp; kwargs...)`` (src/solver.jl:405-409): construct, solve, release; returns the result
+def solve(qp: DeviceQP, backend=None, **opts):
+    """Convenience (no counterpart in the reference, whose callers write ``MPCSolver(qp; ...)`` then ``solve!``,
+    test/runtests.jl:63-66): construct, ``solve!`` (src/solver.jl:347-403), release; returns the result
     dictionary of :meth:`MPCSolver.result`."""
     from .backend import HipBackend
 

@@ -73,11 +73,11 @@ def test_golden_traces(hip, name, driver):
     assert np.max(np.abs(r["solution"] - np.array(g["solution"]))) <= 1e-7
 
 
-def test_madipm_convenience_call(hip):
-    """MadIPM.madipm(qp; kwargs...): one call, result with status / objective / counters."""
-    r = M.madipm(to_device(Q.hs21(), hip), hip, regularization=M.FixedRegularization(1e-8, -1e-8))
+def test_one_call_solve(hip):
+    """M.solve(qp, ...): MPCSolver + solve! + release in one call; result with status / objective / total_time."""
+    r = M.solve(to_device(Q.hs21(), hip), hip, regularization=M.FixedRegularization(1e-8, -1e-8))
     assert r["status"] == M.SOLVE_SUCCEEDED and abs(r["objective"] + 99.96) < 1e-6 and r["total_time"] > 0
-    r2 = M.madipm(to_device(Q.hs21(), hip), regularization=M.FixedRegularization(1e-8, -1e-8))  # own backend
+    r2 = M.solve(to_device(Q.hs21(), hip), regularization=M.FixedRegularization(1e-8, -1e-8))  # own backend
     assert r2["iter"] == r["iter"]
 
 
