@@ -502,7 +502,7 @@ class MPCSolver:
 
 def solve(qp: DeviceQP, backend=None, **opts):
     """Convenience (no counterpart in the reference, whose callers write ``MPCSolver(qp; ...)`` then ``solve!``,
-    test/runtests.jl:63-66): construct, ``solve!`` (src/solver.jl:347-403), release; returns the result
+    test/runtests.jl:13-14): construct, ``solve!`` (src/solver.jl:347-403), release; returns the result
     dictionary of :meth:`MPCSolver.result`."""
     from .backend import HipBackend
 

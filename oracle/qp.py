@@ -199,13 +199,14 @@ def random_qp(seed: int, n: int, m: int, lp: bool = False, pattern_seed=None) ->
                    x0=np.zeros(n), name=f"random-n{n}-m{m}-s{seed}")
 
 
-def dummy_qp(n: int, m: int, seed: int = 1, equality_cons=()) -> DenseQP:
+def dummy_qp(n: int, m: int, seed: int = 1, equality_cons=(), fixed_variables=()) -> DenseQP:
     """Small QP in the spirit of ``MadNLPTests.DenseDummyQP`` (``test/runtests.jl:9``).
 
     The Julia fixture draws from Julia's RNG and cannot be reproduced here
     (SURVEY.md 8c); the structure is kept: ``P = G + G' + 100 I``, bidiagonal
     ``A`` (``A[j, j] = 1, A[j, j+1] = -1``), ``0 <= x <= 1``, ``0 <= Ax <= 1``,
-    rows in ``equality_cons`` become equalities at their lower bound (x_j = x_{j+1}).
+    rows in ``equality_cons`` become equalities at their lower bound (x_j = x_{j+1}), variables in
+    ``fixed_variables`` are fixed at their lower bound (the cases named at ``test/runtests.jl:63-75``).
     """
     G = gen_normal(stream_key(seed, STREAM_H), np.arange(n * n, dtype=U64)).reshape(n, n)
     H = G + G.T + 100.0 * np.eye(n)
@@ -216,7 +217,9 @@ def dummy_qp(n: int, m: int, seed: int = 1, equality_cons=()) -> DenseQP:
     lcon, ucon = np.zeros(m), np.ones(m)
     for j in equality_cons:
         ucon[j] = lcon[j]
-    return DenseQP(H, gen_q(seed, n), A, np.zeros(n), np.ones(n), lcon, ucon, np.zeros(n),
+    uvar = np.ones(n)
+    uvar[list(fixed_variables)] = 0.0
+    return DenseQP(H, gen_q(seed, n), A, np.zeros(n), uvar, lcon, ucon, np.zeros(n),
                    name=f"dummy-n{n}-m{m}")
 
 

@@ -91,3 +91,18 @@ def test_fixed_variables_relax_bound(hip):
     s.close()
     same(r, mpc.solve(lp, kkt_system="normal", regularization=mpc.FixedRegularization(1e-8, 0.0),
                       fixed_variable_treatment="relax_bound"), "fixed variable, normal equations")
+
+
+@pytest.mark.parametrize("eq", [(), (0, 1, 2, 7)])
+def test_dummy_qp_with_fixed_variables(hip, eq):
+    """The cases test/runtests.jl:71-75 names (DenseDummyQP n = 20, m = 15, fixed variables 1, 2, with and without
+    equality rows 1, 2, 3, 8), through the condensed system with RelaxBound."""
+    qp = Q.dummy_qp(20, 15, equality_cons=eq, fixed_variables=(0, 1))
+    ref = mpc.solve(qp, kkt_system="K2", regularization=OREG, fixed_variable_treatment="relax_bound")
+    for driver in ("python", "native"):
+        s = M.MPCSolver(to_device(qp, hip), hip, regularization=REG, driver=driver)
+        r = s.solve()
+        s.close()
+        assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
+        assert abs(r["objective"] - ref["objective"]) < 1e-5 and np.max(np.abs(r["solution"] - ref["solution"])) < 1e-5
+        assert np.max(np.abs(r["solution"][:2])) < 1e-7
