@@ -490,8 +490,12 @@ class MPCSolver:
         h = lambda t: t.detach().cpu().numpy().copy()
         cs = h(self.con_scale) if self.con_scale is not None else np.ones(self.m)
         x = h(st.x[:nx])
+        # stats.constraints = A x of the unscaled model, from c = (A x - s - rhs) of the scaled one
+        cons = h(st.c) + h(st.rhs)
+        cons[self.ind_ineq] += h(st.x[nx:])
         return dict(
             status=self.status, iter=self.k, objective=self.obj_val / self.obj_scale, solution=x,
+            constraints=cons / cs,
             multipliers=h(st.y) * cs / self.obj_scale,
             multipliers_L=h(st.zl[:nx]) / self.obj_scale,
             multipliers_U=h(st.zu[:nx]) / self.obj_scale,

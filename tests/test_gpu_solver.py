@@ -106,6 +106,7 @@ def test_synthetic_vs_oracle(hip, n, m, ncorr, driver):
     assert close(r["objective"], ref["objective"], 1e-9)
     assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
     assert np.max(np.abs(r["multipliers"] - ref["multipliers"])) <= 1e-6
+    assert np.max(np.abs(r["constraints"] - ref["constraints"])) <= 1e-6  # stats.constraints (test/runtests.jl:18)
 
 
 @DRIVERS
@@ -136,6 +137,7 @@ def test_regularizations(hip, reg, driver):
     assert abs(r["objective"] - sol_ref["objective"]) < 1e-6
     assert np.max(np.abs(r["solution"] - sol_ref["solution"])) < 1e-6
     assert np.max(np.abs(r["multipliers"] - sol_ref["multipliers"])) < 1e-6
+    assert np.max(np.abs(r["constraints"] - sol_ref["constraints"])) < 1e-6  # test/runtests.jl:131
 
 
 @pytest.mark.parametrize("with_eq", [False, True])
