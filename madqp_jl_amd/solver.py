@@ -501,6 +501,7 @@ class MPCSolver:
             multipliers_U=h(st.zu[:nx]) / self.obj_scale,
             trace=self.trace, n_factorizations=self.kkt.n_factorizations if self.kkt else 0,
             total_time=getattr(self, "total_time", 0.0),
+            primal_feas=self.inf_pr, dual_feas=self.inf_du,  # stats.primal_feas / dual_feas of MadNLP.update!
         )
 
 
