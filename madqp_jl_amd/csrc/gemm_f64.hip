@@ -700,10 +700,11 @@ __global__ __launch_bounds__(256) void mfma_f64_probe_kernel(int iters, double* 
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
     const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    // inline asm pins the accumulators in VGPRs: with the builtin the compiler parks them in AGPRs and the
+    // loop measures its accvgpr copies (47 instead of 77.7 TFLOP/s; tools/mfma_probe.hip)
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
     }
     double s = 0.0;
 #pragma unroll
