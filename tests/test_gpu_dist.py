@@ -17,7 +17,7 @@ def close(a, b, tol):
     return abs(a - b) <= tol * max(1.0, abs(a), abs(b))
 
 
-@pytest.mark.parametrize("world,port", [(2, 29531), (3, 29533)])
+@pytest.mark.parametrize("world,port", [(2, 29531), (3, 29533), (4, 29535)])
 def test_distributed_kkt_on_one_gpu(tmp_path, world, port):
     out = str(tmp_path / "rec")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
