@@ -42,6 +42,9 @@ def parse():
     p.add_argument("--kkt", choices=("local", "distributed"), default="local",
                    help="local: every GPU solves its own QP (weak scaling, the headline); distributed: all "
                         "GPUs share ONE QP through the panel-cyclic distributed Cholesky (strong scaling)")
+    p.add_argument("--kkt-system", choices=("condensed", "augmented"), default="condensed",
+                   help="condensed (headline): K = H + Sigma_x + A' Theta A, Cholesky; augmented: the K2 form "
+                        "[H + Sigma_x, A'; A, -D], L diag(I,-I) L' (reported with its own flop count)")
     p.add_argument("--panel-width", type=int, default=None, help="block-column width of --kkt distributed")
     p.add_argument("--no-distributed-extra", action="store_true",
                    help="N > 1: skip the additional strong-scaling measurement of the distributed KKT path")
@@ -185,7 +188,7 @@ def measure(args, M, be, world, seed, distributed):
                          regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12,
                          max_ncorr=args.max_ncorr, scaling=True, distributed=distributed,
                          panel_width=args.panel_width if distributed else None,
-                         driver="python" if distributed else args.driver)
+                         driver="python" if distributed else args.driver, kkt_system=args.kkt_system)
     solver.initialize()
     excluded = 0.0  # time of re-initialisations inside the timed region (none unless it converges)
 
@@ -260,6 +263,8 @@ def main():
         gemm_ms = prof["syrk"][0] + prof["potrf_gemm"][0] + prof["potrf_trsm"][0]
         gemm_launches = prof["syrk"][1] + prof["potrf_gemm"][1] + prof["potrf_trsm"][1]
         alg_flops = nfact * (m * nx * nx + nx ** 3 / 3.0)  # SYRK m nx^2 + POTRF nx^3/3
+        if args.kkt_system == "augmented":  # no SYRK; L diag(I,-I) L' of order nx + m
+            alg_flops = nfact * (nx + m) ** 3 / 3.0
         if shared:
             alg_flops /= world  # rank 0's share of the MFMA work (cyclic deal of the block columns)
         achieved = alg_flops / (gemm_ms * 1e-3) * 1e-12 if gemm_ms > 0 else 0.0
@@ -285,6 +290,7 @@ def main():
                                    f"{what}, max_ncorr={args.max_ncorr}",
                        "nx": nx, "m": m, "n_slack": m, "max_ncorr": args.max_ncorr,
                        "driver": "python" if shared else args.driver, "kkt": args.kkt,
+                       "kkt_system": args.kkt_system,
                        "options": "scripts/benchmarks_cpu.jl:35-44 with kkt_system=HIPCondensedKKTSystem, "
                                   "linear_solver=HIPCholeskySolver"},
             "kkt_factor_solve_ms": {

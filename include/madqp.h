@@ -104,6 +104,12 @@ int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, const doubl
  * contract used at src/KKT/normalkkt.jl:99-101,196 and src/linear_solver.jl:10-11. */
 int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out);
 int32_t madqp_chol_destroy(madqp_chol* s);
+/* Quasi-definite mode (the inertia MadNLP's K2 systems have, is_inertia_correct at src/KKT/normalkkt.jl:132-134
+ * generalised to (npos, 0, n - npos)): the matrix given to madqp_chol_factor holds [P, .; B, Q] (lower triangle,
+ * P of order npos, P and Q positive definite) and stands for M = [P, B'; B, -Q]; factor computes M = L diag(I, -I) L',
+ * solve applies M^-1.  npos: a multiple of 128, or n (plain Cholesky, the default).  info as for Cholesky
+ * (the first column whose pivot is not positive). */
+int32_t madqp_chol_set_signature(madqp_chol* s, int64_t npos);
 /* MadNLP.factorize!: in-place lower Cholesky of the n x n matrix at A (blocked left-looking,
  * MFMA panel updates).  info_host: 0 = success, j>0 = leading minor of order j not positive
  * definite (LAPACK dpotrf convention; maps to is_factorized, src/utils.jl:54-62). */
@@ -220,6 +226,15 @@ int32_t madqp_kkt_create(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
 int32_t madqp_kkt_create_normal(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
                                 const int64_t* ind_ineq_host, const double* At, int64_t ldat,
                                 madqp_kkt** out);
+/* The K2 form of MadNLP's default SparseKKTSystem (src/utils.jl:108; augmented system of
+ * test/runtests.jl:102-115,165-180) with the slack block eliminated: [H + Sigma_x, A'; A, -D] of order
+ * ceil128(nx) + m, D_i = 1/Sigma_s,k - dc_i (inequality row) or -dc_i (equality row).  Quasi-definite:
+ * factorised as L diag(I, -I) L' without pivoting (madqp_chol_set_signature); equality rows need no dual
+ * regularization when they are linearly independent.  Operands as madqp_kkt_create (H may be NULL; a
+ * diagonal Hessian goes through madqp_kkt_set_hdiag).  Answers the same madqp_kkt_* calls. */
+int32_t madqp_kkt_create_augmented(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
+                                   const int64_t* ind_ineq_host, const double* H, int64_t ldh,
+                                   const double* A, int64_t lda, madqp_kkt** out);
 int32_t madqp_kkt_destroy(madqp_kkt* kkt);
 /* MadNLP.build_kkt! (src/KKT/normalkkt.jl:166-180): Theta from pr_diag/du_diag, then the SYRK */
 int32_t madqp_kkt_build(madqp_kkt* kkt, const madqp_state* st);

@@ -132,6 +132,12 @@ function MadNLP.create_kkt_system(
     return kkt
 end
 
+# The K2 form (MadNLP's default SparseKKTSystem, src/utils.jl:108) is the same glue with
+# `:madqp_kkt_create_augmented` in the ccall above (same argument list) -- the object then answers every
+# madqp_kkt_* call below as [H + Sigma_x, A'; A, -D] factorised L diag(I,-I) L'; its linear solver reports
+# inertia (nx, 0, m) and `is_inertia_correct(kkt, p, z, n) = (z == 0) && (n == kkt.m)`; equality rows need
+# no dual regularization (the reference's default FixedRegularization(1e-8, 0.0) works as is).
+
 MadNLP.num_variables(kkt::HIPCondensedKKTSystem) = kkt.n
 MadNLP.get_jacobian(kkt::HIPCondensedKKTSystem) = kkt.jac
 MadNLP.get_hessian(kkt::HIPCondensedKKTSystem) = kkt.hess

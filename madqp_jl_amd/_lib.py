@@ -86,6 +86,7 @@ _SIGNATURES = {
     "madqp_syrk_assemble": [vp, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64],
     "madqp_chol_create": [vp, i64, C.POINTER(vp)],
     "madqp_chol_destroy": [vp],
+    "madqp_chol_set_signature": [vp, i64],
     "madqp_chol_factor": [vp, vp, i64, pi32],
     "madqp_chol_solve": [vp, vp],
     "madqp_gemv": [vp, i32, i64, i64, f64, vp, i64, vp, f64, vp],
@@ -118,6 +119,7 @@ _SIGNATURES = {
     "madqp_sp_check": [vp, pstate, pi32],
     "madqp_kkt_create": [vp, i64, i64, i64, pi64, vp, i64, vp, i64, C.POINTER(vp)],
     "madqp_kkt_create_normal": [vp, i64, i64, i64, pi64, vp, i64, C.POINTER(vp)],
+    "madqp_kkt_create_augmented": [vp, i64, i64, i64, pi64, vp, i64, vp, i64, C.POINTER(vp)],
     "madqp_kkt_destroy": [vp],
     "madqp_kkt_build": [vp, pstate],
     "madqp_kkt_factorize": [vp, pi32],

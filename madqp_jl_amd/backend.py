@@ -154,6 +154,10 @@ class HipBackend:
     def chol_destroy(self, h):
         self.lib.madqp_chol_destroy(h)
 
+    def chol_set_signature(self, h, npos):
+        """Quasi-definite mode: the stored [P, .; B, Q] stands for [P, B'; B, -Q], P of order ``npos``."""
+        self._ck(self.lib.madqp_chol_set_signature(h, npos))
+
     def chol_factor(self, h, A, lda) -> int:
         info = C.c_int32()
         self._ck(self.lib.madqp_chol_factor(h, ptr(A), lda, C.byref(info)))
@@ -274,6 +278,13 @@ class HipBackend:
         arr = (C.c_int64 * max(ns, 1))(*[int(i) for i in ind_ineq])
         h = C.c_void_p()
         self._ck(self.lib.madqp_kkt_create(self.ctx, nx, m, ns, arr, ptr(H), ldh, ptr(A), lda, C.byref(h)))
+        return h
+
+    def kkt_create_augmented(self, nx, m, ind_ineq, H, ldh, A, lda):
+        ns = len(ind_ineq)
+        arr = (C.c_int64 * max(ns, 1))(*[int(i) for i in ind_ineq])
+        h = C.c_void_p()
+        self._ck(self.lib.madqp_kkt_create_augmented(self.ctx, nx, m, ns, arr, ptr(H), ldh, ptr(A), lda, C.byref(h)))
         return h
 
     def kkt_create_normal(self, nx, m, ind_ineq, At, ldat):

@@ -391,6 +391,10 @@ __device__ __forceinline__ void sweep_diag_publish(const double2_t (&w0)[4], con
     }
 }
 
+__global__ __launch_bounds__(256) void negate_kernel(double* __restrict__ v, int64_t len) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) v[i] = -v[i];
+}
+
 __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __restrict__ L, int64_t lda,
                                                               const double* __restrict__ winv,
                                                               const double* __restrict__ b,
@@ -542,6 +546,7 @@ extern "C" int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out
     if (!s) return madqp_fail(ctx, MADQP_ERR_ALLOC, "host allocation failed");
     s->ctx = ctx;
     s->n = n;
+    s->npos = n;
     s->factored = false;
     s->A = nullptr;
     s->lda = 0;
@@ -559,6 +564,17 @@ extern "C" int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out
                           hipGetErrorString(e));
     }
     *out = s;
+    return MADQP_OK;
+}
+
+// Quasi-definite mode: the matrix handed to madqp_chol_factor is [P, .; B, Q] (lower triangle, P of order npos
+// and Q positive definite) and stands for [P, B'; B, -Q]; factor computes L with [P, B'; B, -Q] = L diag(I_npos, -I) L',
+// solve applies the inverse of that matrix.  npos a multiple of 128 (or n, which restores plain Cholesky).
+extern "C" int32_t madqp_chol_set_signature(madqp_chol* s, int64_t npos) {
+    if (!s) return MADQP_ERR_ARG;
+    ARG_TRY(s->ctx, npos >= 0 && npos <= s->n && (npos % NB == 0 || npos == s->n));
+    s->npos = npos;
+    s->factored = false;
     return MADQP_OK;
 }
 
@@ -594,9 +610,10 @@ static int64_t outer_panel_width(int64_t rows, bool has_update, int64_t slots) {
 }
 
 static int32_t panel_update(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t row0,
-                            int64_t k0, int64_t width, int64_t kend = -1) {
-    // C[row0:n, row0:row0+width] -= L[row0:n, k0:kend] * L[row0:row0+width, k0:kend]'   (kend = row0
-    // unless given: the distributed factorisation applies one received panel at a time)
+                            int64_t k0, int64_t width, int64_t kend = -1, double alpha = -1.0) {
+    // C[row0:n, row0:row0+width] += alpha L[row0:n, k0:kend] * L[row0:row0+width, k0:kend]'   (kend = row0
+    // unless given: the distributed factorisation applies one received panel at a time; alpha = +1: the
+    // columns of the positive block applied to the negative block of a quasi-definite matrix)
     if (kend < 0) kend = row0;
     GemmArgs g{};
     g.X = A + row0 + k0 * lda;
@@ -607,7 +624,7 @@ static int32_t panel_update(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, i
     g.ldc = lda;
     g.Cin = g.C;
     g.ldcin = lda;
-    g.alpha = -1.0;
+    g.alpha = alpha;
     g.beta = 1.0;
     g.M = n - row0;
     g.N = width;
@@ -687,14 +704,24 @@ extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int3
         return MADQP_OK;
     }
     HIP_TRY(ctx, hipMemsetAsync(s->d_info, 0, sizeof(int32_t), ctx->stream));
+    // Quasi-definite mode (npos < n): A = [P, .; B, -Q] with P, Q positive definite and Q's block STORED AS +Q.
+    // A = L diag(I, -I) L' with L = [L11, 0; W, L22], W = B L11^-T, L22 L22' = Q + W W': the same left-looking
+    // sweep, except that an outer panel of the second block receives the columns of the first with a plus sign
+    // (and never straddles the boundary).  No pivoting: stable for quasi-definite matrices.
+    const int64_t npos = s->npos;
     int64_t W = 0;
     for (int64_t J0 = 0; J0 < n; J0 += W) {
         W = std::min<int64_t>(outer_panel_width(n - J0, J0 > 0, ctx->gemm_slots), n - J0);
-        if (J0 > 0) {
-            int32_t r = panel_update(ctx, A, lda, n, J0, 0, W);
-            if (r) return r;
+        if (J0 < npos && J0 + W > npos) W = npos - J0;
+        int32_t r = MADQP_OK;
+        if (J0 > 0 && J0 < npos) {
+            r = panel_update(ctx, A, lda, n, J0, 0, W);
+        } else if (J0 > 0) {
+            if (npos > 0) r = panel_update(ctx, A, lda, n, J0, 0, W, npos, 1.0);
+            if (!r && J0 > npos) r = panel_update(ctx, A, lda, n, J0, npos, W);
         }
-        int32_t r = factor_range(s, A, lda, J0, W);
+        if (r) return r;
+        r = factor_range(s, A, lda, J0, W);
         if (r) return r;
     }
     int32_t info = 0;
@@ -821,6 +848,7 @@ extern "C" int32_t madqp_chol_factor_begin(madqp_chol* s, double* A, int64_t lda
     if (!s) return MADQP_ERR_ARG;
     madqp_ctx* ctx = s->ctx;
     ARG_TRY(ctx, A && lda >= s->n);
+    ARG_TRY(ctx, s->npos == s->n);  // the panel pieces factor positive definite matrices only
     s->factored = false;
     s->A = A;
     s->lda = lda;
@@ -948,6 +976,12 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
         hipLaunchKernelGGL(trsv_fwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, A, lda, s->winv, rhs,
                            s->tmp, n, s->d_info, vec);
         LAUNCH_CHECK(ctx);
+        if (s->npos < n) {  // y <- diag(I, -I) y
+            const int64_t len = n - s->npos;
+            hipLaunchKernelGGL(negate_kernel, dim3((unsigned)std::min<int64_t>((len + 255) / 256, 1024)), dim3(256), 0,
+                               ctx->stream, s->tmp + s->npos, len);
+            LAUNCH_CHECK(ctx);
+        }
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)rhs, 0x7FF8A5A5, 2 * (size_t)n, ctx->stream));
         hipLaunchKernelGGL(trsv_bwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, A, lda, s->winv,
                            s->tmp, rhs, n, s->d_info, vec);

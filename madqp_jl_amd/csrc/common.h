@@ -144,4 +144,5 @@ struct madqp_chol {
     double* A;  // last factored matrix (borrowed)
     int64_t lda;
     bool factored;
+    int64_t npos;  // quasi-definite mode (madqp_chol_set_signature): A = L diag(I_npos, -I) L'; npos == n: Cholesky
 };

@@ -13,6 +13,12 @@
 // src/KKT/normalkkt.jl:166-205, LP only as there (:45-48), dual regularization not added to the
 // matrix.  It needs A' with row k (a variable) contiguous, which is again the
 // k-major layout the GEMM core consumes; equality rows need no regularization in this form.
+//
+// Mode AUGMENTED is the K2 form of MadNLP's default SparseKKTSystem (src/utils.jl:108) with only the slack block
+// eliminated:  [H + Sigma_x, A'; A, -D],  D_i = 1/S_k - dc_i (inequality row) or -dc_i (equality row), order
+// nx + m.  It is quasi-definite, so L diag(I, -I) L' without pivoting is stable (madqp_chol_set_signature), and
+// equality rows need no dual regularization when A_eq has full row rank:
+//   [H + Sigma_x, A'; A, -D] [dx; dy] = [r1_x; r2 + r1_s / S],   ds = (r1_s + dy) / S
 #include <algorithm>
 
 #include "common.h"
@@ -20,7 +26,7 @@
 #define TPB 256
 #define MADQP_MAX_BLOCKS 1024
 
-enum { KKT_CONDENSED = 0, KKT_NORMAL = 1 };
+enum { KKT_CONDENSED = 0, KKT_NORMAL = 1, KKT_AUGMENTED = 2 };
 
 struct madqp_kkt {
     madqp_ctx* ctx;
@@ -43,6 +49,8 @@ struct madqp_kkt {
     double* K;
     int64_t ldk;
     double *theta, *t, *u;  // m
+    int64_t np;             // augmented mode: nx rounded up to a multiple of 128 = row of the first constraint
+    double* b;              // augmented mode: right-hand side of order np + m
     madqp_chol* chol;
 };
 
@@ -56,6 +64,47 @@ inline int grid_for(int64_t len) {
 }
 
 #include "kkt_kernels.inc"
+
+// Lower triangle of the augmented matrix, one 64 x 64 tile per workgroup (blockIdx.x = tile row, .y = tile column):
+//   rows/cols [0, nx): H + diag(dx);  [nx, np): identity (padding up to a block boundary);
+//   rows np + r, cols [0, nx): A[r, :] (A is row-major: transposed through LDS);  rows/cols np + r: diag(dd).
+__global__ __launch_bounds__(256) void aug_fill_kernel(int64_t nx, int64_t np, int64_t m, const double* __restrict__ H,
+                                                       int64_t ldh, const double* __restrict__ hdiag,
+                                                       const double* __restrict__ dx, const double* __restrict__ A,
+                                                       int64_t lda, const double* __restrict__ dd,
+                                                       double* __restrict__ K, int64_t ldk) {
+    const int64_t ti = blockIdx.x, tj = blockIdx.y;
+    if (tj > ti) return;
+    const int64_t i0 = ti * 64, j0 = tj * 64, N = np + m;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    __shared__ double tile[64][65];
+    if (i0 >= np && j0 < np) {  // constraint rows x variable columns
+        const int64_t r0 = i0 - np;
+        for (int rr = ty; rr < 64; rr += 4) {
+            const int64_t r = r0 + rr, j = j0 + tx;
+            tile[rr][tx] = (r < m && j < nx) ? A[r * lda + j] : 0.0;
+        }
+        __syncthreads();
+        const int64_t i = i0 + tx;
+        if (i < N)
+            for (int c = ty; c < 64; c += 4) K[i + (j0 + c) * ldk] = tile[tx][c];
+        return;
+    }
+    const int64_t i = i0 + tx;
+    if (i >= N) return;
+    for (int c = ty; c < 64; c += 4) {
+        const int64_t j = j0 + c;
+        if (j > i) continue;
+        double v = 0.0;
+        if (i < nx) {
+            if (H) v = H[i + j * ldh];
+            if (i == j) v += dx[i] + (hdiag ? hdiag[i] : 0.0);
+        } else if (i == j) {
+            v = (i < np) ? 1.0 : dd[i - np];
+        }
+        K[i + j * ldk] = v;
+    }
+}
 }  // namespace
 
 #define KLAUNCH(kern, len, ...)                                                                 \
@@ -91,6 +140,7 @@ extern "C" int32_t madqp_kkt_destroy(madqp_kkt* k) {
     if (k->sg) (void)hipFree(k->sg);
     if (k->dn) (void)hipFree(k->dn);
     if (k->tn) (void)hipFree(k->tn);
+    if (k->b) (void)hipFree(k->b);
     delete k;
     return MADQP_OK;
 }
@@ -123,7 +173,9 @@ static int32_t kkt_create_common(madqp_ctx* ctx, int mode, int64_t nx, int64_t m
     k->lda = lda;
     k->At = At;
     k->ldat = ldat;
-    const int64_t dim = (mode == KKT_NORMAL) ? m : nx;  // order of the matrix that is factorised
+    k->np = (nx + 127) / 128 * 128;
+    // order of the matrix that is factorised
+    const int64_t dim = (mode == KKT_NORMAL) ? m : (mode == KKT_AUGMENTED) ? k->np + m : nx;
     const int64_t n = nx + ns;
     // leading dimension and column count padded to a multiple of 128 (zero filled): every GEMM tile
     // of the factorisation is a full tile (see GemmArgs::Mread)
@@ -141,6 +193,7 @@ static int32_t kkt_create_common(madqp_ctx* ctx, int mode, int64_t nx, int64_t m
     if (e == hipSuccess) e = hipMalloc(&k->u, mb);
     if (e == hipSuccess && mode == KKT_NORMAL) e = hipMalloc(&k->dn, nb);
     if (e == hipSuccess && mode == KKT_NORMAL) e = hipMalloc(&k->tn, nb);
+    if (e == hipSuccess && mode == KKT_AUGMENTED) e = hipMalloc(&k->b, (size_t)std::max<int64_t>(dim, 1) * sizeof(double));
     if (e == hipSuccess && ns)
         e = hipMemcpy(k->d_ind_ineq, ind_ineq_host, ns * sizeof(int64_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && m)
@@ -151,6 +204,7 @@ static int32_t kkt_create_common(madqp_ctx* ctx, int mode, int64_t nx, int64_t m
                           (long long)nx, (long long)m, hipGetErrorString(e));
     }
     int32_t r = madqp_chol_create(ctx, dim, &k->chol);
+    if (!r && mode == KKT_AUGMENTED) r = madqp_chol_set_signature(k->chol, k->np);
     if (r) {
         madqp_kkt_destroy(k);
         return r;
@@ -208,6 +262,17 @@ extern "C" int32_t madqp_kkt_set_hdiag(madqp_kkt* k, const double* hdiag) {
     return MADQP_OK;
 }
 
+// Augmented (K2) system [H + Sigma_x, A'; A, -D] of order ceil128(nx) + m; same operands as madqp_kkt_create.
+// H may be NULL (LP, or a diagonal Hessian through madqp_kkt_set_hdiag).
+extern "C" int32_t madqp_kkt_create_augmented(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
+                                              const int64_t* ind_ineq_host, const double* H, int64_t ldh,
+                                              const double* A, int64_t lda, madqp_kkt** out) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, !H || ldh >= nx);
+    ARG_TRY(ctx, m == 0 || nx == 0 || (A && lda >= nx));
+    return kkt_create_common(ctx, KKT_AUGMENTED, nx, m, ns, ind_ineq_host, H, ldh, A, lda, nullptr, 0, out);
+}
+
 extern "C" int32_t madqp_kkt_create_normal(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
                                            const int64_t* ind_ineq_host, const double* At,
                                            int64_t ldat, madqp_kkt** out) {
@@ -250,6 +315,18 @@ static int32_t kkt_build_impl(madqp_kkt* k, const madqp_state* st, int64_t nrang
         return madqp_syrk_assemble_ranges(ctx, k->m, k->nx, k->At, k->ldat, k->dn, nullptr, 0, k->theta,
                                           k->K, k->ldk, nranges, ranges);
     }
+    if (k->mode == KKT_AUGMENTED) {
+        ARG_TRY(ctx, ranges == nullptr);
+        const int64_t N = k->np + k->m;
+        if (N == 0) return MADQP_OK;
+        ProfScope ps(ctx, MADQP_PROF_SYRK);
+        if (k->m) KLAUNCH(aug_diag_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, k->theta);
+        const unsigned tiles = (unsigned)((N + 63) / 64);
+        hipLaunchKernelGGL(aug_fill_kernel, dim3(tiles, tiles), dim3(256), 0, ctx->stream, k->nx, k->np, k->m, k->H,
+                           k->ldh, k->hdiag, st->pr_diag, k->A, k->lda, k->theta, k->K, k->ldk);
+        LAUNCH_CHECK(ctx);
+        return MADQP_OK;
+    }
     {
         ProfScope ps(ctx, MADQP_PROF_VEC);
         if (k->m) KLAUNCH(theta_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, k->theta);
@@ -283,7 +360,7 @@ extern "C" int32_t madqp_kkt_build_cols(madqp_kkt* k, const madqp_state* st, int
 extern "C" int32_t madqp_kkt_chol(madqp_kkt* k, madqp_chol** chol, int64_t* order) {
     if (!k || !chol) return MADQP_ERR_ARG;
     *chol = k->chol;
-    if (order) *order = (k->mode == KKT_NORMAL) ? k->m : k->nx;
+    if (order) *order = (k->mode == KKT_NORMAL) ? k->m : (k->mode == KKT_AUGMENTED) ? k->np + k->m : k->nx;
     return MADQP_OK;
 }
 
@@ -316,6 +393,19 @@ extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* 
             ProfScope ps(ctx, MADQP_PROF_VEC);
             if (k->ns) KLAUNCH(jt_slack_kernel, k->ns, k->ns, k->d_ind_ineq, wy, k->tn + k->nx, 1.0, 0.0);
             if (st->n) KLAUNCH(normal_back_kernel, st->n, st->n, k->tn, k->hdiag ? k->sg : st->pr_diag, wx);
+        }
+        return madqp_finish_aug_solve(ctx, st, w);
+    }
+    if (k->mode == KKT_AUGMENTED) {
+        const int64_t N = k->np + k->m;
+        if (N) {
+            ProfScope ps(ctx, MADQP_PROF_VEC);
+            KLAUNCH(aug_rhs_kernel, N, k->nx, k->np, k->m, k->d_slot, st->pr_diag, wx, wy, k->b);
+        }
+        if ((r = madqp_chol_solve(k->chol, k->b))) return r;
+        if (k->nx + k->m) {
+            ProfScope ps(ctx, MADQP_PROF_VEC);
+            KLAUNCH(aug_back_kernel, k->nx + k->m, k->nx, k->np, k->m, k->d_slot, st->pr_diag, k->b, wx, wy);
         }
         return madqp_finish_aug_solve(ctx, st, w);
     }

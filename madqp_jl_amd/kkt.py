@@ -38,6 +38,21 @@ class HIPCholeskySolver:
         return (n, 0, 0) if self.info == 0 else (self.info - 1, 0, 1)
 
 
+class HIPQuasiDefiniteSolver(HIPCholeskySolver):
+    """The same blocked factorisation in quasi-definite mode (``madqp_chol_set_signature``): ``L diag(I, -I) L'`` of
+    the augmented matrix, inertia (nx, 0, m) when every pivot has the expected sign."""
+
+    def __init__(self, backend, kkt_handle, nx, m):
+        super().__init__(backend, kkt_handle)
+        self.nx, self.m = nx, m
+
+    def introduce(self) -> str:
+        return "madqp-hip blocked left-looking fp64 L diag(I,-I) L' (quasi-definite, MFMA, gfx950)"
+
+    def inertia(self, n=None):
+        return (self.nx, 0, self.m) if self.info == 0 else (0, 1, 0)
+
+
 class HIPCondensedKKTSystem:
     """Dense condensed KKT system ``K = H + Sigma_x + A' Theta A`` on the device.
 
@@ -140,6 +155,38 @@ class HIPNormalKKTSystem(HIPCondensedKKTSystem):
 
     def is_inertia_correct(self, num_pos, num_zero, num_neg):  # src/KKT/normalkkt.jl:132-134
         return num_zero == 0 and num_pos == self.m
+
+
+class HIPAugmentedKKTSystem(HIPCondensedKKTSystem):
+    """The K2 form of MadNLP's default ``SparseKKTSystem`` (src/utils.jl:108; the system the reference's tests
+    compare everything against, test/runtests.jl:102-115,165-180) with the slack block eliminated, dense on
+    the device: ``[H + Sigma_x, A'; A, -D]`` of order ``ceil128(nx) + m``, factorised as ``L diag(I, -I) L'``
+    without pivoting (quasi-definite).  Equality rows enter exactly (``D_i = -dc_i``, which may be 0 when the
+    equality rows are linearly independent) -- no ``-1/dc`` weights as in the condensed form.
+
+    ``H``: (nx, nx) tensor, a 1-D tensor (diagonal of H) or None; ``A``: (m, nx) row-major tensor; borrowed.
+    """
+
+    def __init__(self, backend, st: State, nx, ind_ineq, H, A):
+        self.be, self.st = backend, st
+        self.nx, self.m = int(nx), st.m
+        self.ind_ineq = [int(i) for i in ind_ineq]
+        self.ns = len(self.ind_ineq)
+        assert st.n == self.nx + self.ns
+        self.H, self.A = H, A
+        diag = H is not None and H.dim() == 1
+        if H is not None:
+            assert H.is_contiguous() and tuple(H.shape) in ((nx, nx), (nx,))
+        assert A.is_contiguous() and tuple(A.shape) == (self.m, self.nx)
+        self._h = backend.kkt_create_augmented(self.nx, self.m, self.ind_ineq, None if diag else H,
+                                               max(self.nx, 1), A, max(self.nx, 1))
+        if diag:
+            backend.kkt_set_hdiag(self._h, H)
+        self.linear_solver = HIPQuasiDefiniteSolver(backend, self._h, self.nx, self.m)
+        self.n_factorizations = 0
+
+    def is_inertia_correct(self, num_pos, num_zero, num_neg):  # src/KKT/normalkkt.jl:132-134, K2 inertia
+        return num_zero == 0 and num_neg == self.m
 
 
 class _SparseMixin:

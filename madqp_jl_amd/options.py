@@ -42,11 +42,13 @@ class IPMOptions:
         tol=1e-8, max_iter=3000, scaling=True, bound_push=1e-2, bound_fac=1e-2,
         bound_relax_factor=1e-8, max_ncorr=0, mu_init=1e-1, mu_min=1e-11,
         tol_linear_solve=1e-8, check_residual=False, rethrow_error=False, print_level=0,
-        kkt_system="condensed",  # "condensed" (HIPCondensedKKTSystem) or "normal" (HIPNormalKKTSystem, LP)
+        # "condensed" (HIPCondensedKKTSystem), "normal" (HIPNormalKKTSystem, LP) or "augmented" (HIPAugmentedKKTSystem:
+        # the K2 form, equality rows without dual regularization)
+        kkt_system="condensed",
         # MadNLP.RelaxBound ("relax_bound": a fixed variable keeps both bounds, relaxed by bound_relax_factor like any
         # other) is what the reference selects for condensed KKT systems, MakeParameter otherwise (src/utils.jl:81);
-        # elimination of fixed variables is not implemented: None = "relax_bound" for the condensed system, "error"
-        # for the normal equations
+        # elimination of fixed variables is not implemented: None = "relax_bound" for the condensed and augmented
+        # systems, "error" for the normal equations
         fixed_variable_treatment=None,
         distributed=False,  # True: assembly + Cholesky shared by the ranks of torch.distributed (dist.py)
         panel_width=None,  # block-column width of the distributed factorisation (multiple of 128)

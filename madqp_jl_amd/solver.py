@@ -18,8 +18,8 @@ import numpy as np
 import torch
 
 from ._lib import CMpcInfo, CMpcOptions
-from .kkt import (HIPCondensedKKTSystem, HIPNormalKKTSystem, HIPSparseCondensedKKTSystem,
-                  HIPSparseNormalKKTSystem)
+from .kkt import (HIPAugmentedKKTSystem, HIPCondensedKKTSystem, HIPNormalKKTSystem,
+                  HIPSparseCondensedKKTSystem, HIPSparseNormalKKTSystem)
 from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, FixedRegularization,
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
 from .qp import DeviceCSR, DeviceQP
@@ -91,7 +91,7 @@ class MPCSolver:
         self.qp, self.be = qp, backend
         self.opt = IPMOptions(**opts)
         host = lambda t: t.detach().cpu().numpy()
-        fvt = self.opt.fixed_variable_treatment or ("relax_bound" if self.opt.kkt_system == "condensed" else "error")
+        fvt = self.opt.fixed_variable_treatment or ("relax_bound" if self.opt.kkt_system in ("condensed", "augmented") else "error")
         ic = get_index_constraints(host(qp.lvar), host(qp.uvar), host(qp.lcon), host(qp.ucon), fvt)
         self.ind_ineq, self.ind_eq = ic["ind_ineq"], ic["ind_eq"]
         self.nx, self.ns = qp.nvar, len(self.ind_ineq)
@@ -99,11 +99,14 @@ class MPCSolver:
         self.st = backend.new_state(self.n, self.m, ic["ind_lb"], ic["ind_ub"])
         self.nlb, self.nub = self.st.nlb, self.st.nub
         reg = self.opt.regularization
-        if self.opt.kkt_system not in ("condensed", "normal"):
+        if self.opt.kkt_system not in ("condensed", "normal", "augmented"):
             raise ValueError(f"unknown kkt_system {self.opt.kkt_system!r}")
         diag_h = qp.H is not None and qp.H.dim() == 1  # H = diag(vector): sparse front end only
-        if diag_h and not isinstance(qp.A, DeviceCSR):
-            raise ValueError("a diagonal Hessian (1-D tensor) needs the sparse front end (A as DeviceCSR)")
+        if diag_h and not isinstance(qp.A, DeviceCSR) and self.opt.kkt_system != "augmented":
+            raise ValueError("a diagonal Hessian (1-D tensor) needs the sparse front end (A as DeviceCSR) "
+                             "or kkt_system='augmented'")
+        if self.opt.kkt_system == "augmented" and (isinstance(qp.A, DeviceCSR) or self.opt.distributed):
+            raise ValueError("the augmented KKT system takes a dense Jacobian on one GPU")
         if self.opt.kkt_system == "normal" and qp.H is not None and not diag_h:
             raise ValueError("The KKT system NormalKKTSystem supports only linear programs.")
         if self.opt.kkt_system == "condensed" and len(self.ind_eq) and (
@@ -350,6 +353,8 @@ class MPCSolver:
                 raise ValueError("the sparse front end runs on one GPU")
             cls = HIPSparseNormalKKTSystem if opt.kkt_system == "normal" else HIPSparseCondensedKKTSystem
             self.kkt = cls(be, st, nx, self.ind_ineq, self.H, self.A)
+        elif opt.kkt_system == "augmented":
+            self.kkt = HIPAugmentedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)
         elif opt.kkt_system == "normal":
             self.At = self.A.t().contiguous()  # (nx, m): the layout the normal-equations GEMM consumes
             self.kkt = normal_cls(be, st, nx, self.ind_ineq, self.H, self.At, **extra)

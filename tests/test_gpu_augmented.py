@@ -1,0 +1,174 @@
+"""GPU: the augmented (K2) KKT system -- SURVEY.md 8f rank 4, the form MadNLP's default SparseKKTSystem
+factorises (src/utils.jl:108) and the one the reference's tests compare every other formulation against
+(test/runtests.jl:102-115, 165-180).  On the device: [H + Sigma_x, A'; A, -D] factorised as L diag(I, -I) L'
+without pivoting (madqp_chol_set_signature), checked against the oracle's K2 path (dense LU of the unreduced
+augmented matrix) with the reference's DEFAULT regularization (delta_d = 0), equality rows included."""
+import numpy as np
+import pytest
+import torch
+
+import madqp_jl_amd as M
+from oracle import mpc
+from oracle import qp as Q
+from test_gpu_solver import DRIVERS, close, compare_traces, to_device
+
+pytestmark = pytest.mark.gpu
+
+
+def solve_aug(qp, be, **opts):
+    s = M.MPCSolver(to_device(qp, be), be, kkt_system="augmented", **opts)
+    r = s.solve()
+    s.close()
+    return r
+
+
+@pytest.mark.parametrize("npos,nneg", [(128, 50), (256, 300), (0, 200), (384, 0), (2304, 1500), (1280, 2900)])
+def test_quasidefinite_factor_and_solve(hip, npos, nneg):
+    """madqp_chol in quasi-definite mode against numpy on M = [P, B'; B, -Q] (several outer panels at the two
+    largest sizes; an empty positive / negative block at the edges)."""
+    rng = np.random.default_rng(npos + nneg)
+    n = npos + nneg
+    R = rng.standard_normal((npos, npos)) / np.sqrt(max(npos, 1))
+    P = R @ R.T + 2.0 * np.eye(npos)
+    S = rng.standard_normal((nneg, nneg)) / np.sqrt(max(nneg, 1))
+    Qm = S @ S.T + 0.5 * np.eye(nneg)
+    B = rng.standard_normal((nneg, npos)) / np.sqrt(max(npos, 1))
+    Mfull = np.block([[P, B.T], [B, -Qm]])
+    stored = np.block([[P, np.zeros((npos, nneg))], [B, Qm]])  # what the library is given: +Q in the corner
+    lda = (n + 127) // 128 * 128
+    A = torch.zeros((lda, lda), dtype=torch.float64, device=hip.device)  # column-major: A[j, i] = element (i, j)
+    A[:n, :n] = torch.as_tensor(np.tril(stored).T.copy(), device=hip.device)
+    ch = hip.chol_create(n)
+    hip.chol_set_signature(ch, npos)
+    assert hip.chol_factor(ch, A, lda) == 0
+    b = rng.standard_normal(n)
+    x = torch.as_tensor(b.copy(), device=hip.device)
+    hip.chol_solve(ch, x)
+    hip.sync()
+    ref = np.linalg.solve(Mfull, b)
+    assert np.max(np.abs(x.cpu().numpy() - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref)))
+    # L diag(I, -I) L' reproduces M
+    L = np.tril(A[:n, :n].cpu().numpy().T)
+    sgn = np.r_[np.ones(npos), -np.ones(nneg)]
+    assert np.max(np.abs((L * sgn) @ L.T - Mfull)) <= 1e-11 * np.max(np.abs(Mfull))
+    # a negative block that is not positive definite is reported like a failed Cholesky pivot (1-based column)
+    if nneg >= 50:
+        A.zero_()
+        bad = stored.copy()
+        bad[npos + 40, npos + 40] = -50.0
+        A[:n, :n] = torch.as_tensor(np.tril(bad).T.copy(), device=hip.device)
+        assert hip.chol_factor(ch, A, lda) == npos + 41
+    hip.chol_set_signature(ch, n)  # back to plain Cholesky
+    hip.chol_destroy(ch)
+
+
+@pytest.mark.parametrize("case", ["with_eq", "ineq_only", "lp_eq", "diag_h"])
+def test_augmented_kkt_conformance(hip, case):
+    """MadNLPTests.test_kkt_system (test/runtests.jl:149-163) on the augmented system: K * solve(b) == b through
+    the unreduced mul!, and the solution equals the oracle's K2 LU solve of the same unreduced system."""
+    rng = np.random.default_rng(5)
+    qp = Q.synthetic_qp(7, 90, 35, "lp" if case == "lp_eq" else "wigner")
+    if case in ("with_eq", "lp_eq", "diag_h"):
+        qp.lcon[[3, 10]] = qp.ucon[[3, 10]] = 0.25
+    dq = to_device(qp, hip)
+    if case == "diag_h":
+        qp.H = np.diag(np.diag(qp.H))
+        dq = to_device(qp, hip)
+        dq.H = torch.as_tensor(np.diag(qp.H).copy(), device=hip.device)
+    s = M.MPCSolver(dq, hip, kkt_system="augmented")  # default regularization: delta_d = 0
+    s.initialize()
+    st = s.st
+    ref = mpc.MPCSolver(qp, kkt_system="K2")
+    ref.initialize()
+    # the start point's state (same on both sides: the start point is part of the golden-trace parity)
+    hip.set_aug_diagonal_reg(st, 1e-8, 0.0)
+    ref.del_w, ref.del_c = 1e-8, 0.0
+    ref.set_aug_diagonal_reg()
+    assert np.allclose(st.pr_diag.cpu().numpy(), ref.kkt.pr_diag, rtol=1e-12)
+    s.kkt.factorize_wrapper()
+    assert s.kkt.linear_solver.is_factorized()
+    assert s.kkt.is_inertia_correct(*s.kkt.linear_solver.inertia())
+    ref.kkt.build_and_factorize()
+    b = rng.standard_normal(st.ntot)
+    st.p.copy_(torch.as_tensor(b))
+    hip.copy(st.p, st.d)
+    s.kkt.solve(st.d)
+    hip.fill(0.0, st.w1)
+    s.kkt.mul(st.w1, st.d, 1.0, 0.0)
+    assert np.max(np.abs(st.w1.cpu().numpy() - b)) / max(1.0, np.max(np.abs(b))) < 1e-10
+    w = mpc.KKTVec(ref.n, ref.m, ref.nlb, ref.nub, ref.ind_lb, ref.ind_ub)
+    w.values[:] = b
+    ref.kkt.solve(w)
+    assert np.max(np.abs(st.d.cpu().numpy() - w.values)) <= 1e-9 * max(1.0, np.max(np.abs(w.values)))
+    s.close()
+
+
+@DRIVERS
+@pytest.mark.parametrize("name", ["simple_lp", "hs21", "dummy_20_15_eq", "synthetic_300_120", "lp_400_150"])
+def test_augmented_vs_oracle_k2(hip, name, driver):
+    """Whole solves with the reference's default options (FixedRegularization(1e-8, 0.0)): trace, iteration count
+    and solution follow the oracle's K2 path, the reference's default KKT formulation."""
+    qp = {"simple_lp": Q.simple_lp, "hs21": Q.hs21,
+          "dummy_20_15_eq": lambda: Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)),
+          "synthetic_300_120": lambda: Q.synthetic_qp(20250914, 300, 120),
+          "lp_400_150": lambda: Q.synthetic_qp(5, 400, 150, "lp")}[name]()
+    r = solve_aug(qp, hip, driver=driver)
+    ref = mpc.solve(qp, kkt_system="K2")
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
+    compare_traces(r["trace"], ref["trace"], f"augmented {name}")
+    assert close(r["objective"], ref["objective"], 1e-9)
+    assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+    assert np.max(np.abs(r["multipliers"] - ref["multipliers"])) <= 1e-6
+    if name == "simple_lp":  # test/runtests.jl:165-180
+        assert abs(r["objective"] - 1.0) < 1e-8 and np.allclose(r["solution"], [0.5, 0.5], atol=1e-8)
+
+
+def test_augmented_equals_condensed(hip):
+    """test/runtests.jl:102-115 / 165-180: two KKT formulations of the same QP agree (atol 1e-6), here the
+    augmented and the condensed systems on a QP with equality rows, plus Gondzio corrections."""
+    qp = Q.dummy_qp(30, 12, equality_cons=(1, 5))
+    ra = solve_aug(qp, hip, max_ncorr=3)
+    s = M.MPCSolver(to_device(qp, hip), hip, regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=3)
+    rc = s.solve()
+    s.close()
+    assert ra["status"] == rc["status"] == M.SOLVE_SUCCEEDED
+    assert abs(ra["objective"] - rc["objective"]) < 1e-6
+    assert np.max(np.abs(ra["solution"] - rc["solution"])) < 1e-6
+    assert np.max(np.abs(ra["multipliers"] - rc["multipliers"])) < 1e-5
+
+
+def test_augmented_rejects_what_it_cannot_take(hip):
+    qp = Q.synthetic_qp(3, 30, 10)
+    dq = M.DeviceQP.from_numpy(hip.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0,
+                               sparse=True)
+    with pytest.raises(ValueError):
+        M.MPCSolver(dq, hip, kkt_system="augmented")
+
+
+def test_augmented_full_size_n5k_with_equalities(hip):
+    """BASELINE config 1 (nx=5000, m=2000) with 200 of the rows turned into equalities, default regularization
+    (delta_d = 0): beyond the oracle, so size-independent properties -- convergence, the unreduced residual of the
+    last solve (mul!), and an optimality certificate computed from the returned point alone."""
+    n, m, neq = 5000, 2000, 200
+    dq = M.DeviceQP.synthetic(hip, 20250615, n, m)
+    dq.ucon[:neq] = 0.0  # rows 0..199: A x = 0 (x = 0 is feasible, as for the inequality rows)
+    s = M.MPCSolver(dq, hip, kkt_system="augmented", max_iter=100)
+    assert len(s.ind_eq) == neq and s.ns == m - neq
+    r = s.solve()
+    assert r["status"] == M.SOLVE_SUCCEEDED, (r["status"], r["iter"])
+    t = r["trace"][-1]
+    assert max(t["inf_pr"], t["inf_du"], t["inf_compl"]) <= 1e-8
+    assert s.last_residual_ratio < 1e-7
+    xd = torch.as_tensor(r["solution"], device=hip.device)
+    y, zl, zu = (torch.as_tensor(r[k], device=hip.device) for k in ("multipliers", "multipliers_L", "multipliers_U"))
+    Ax = dq.A @ xd
+    assert float(Ax[:neq].abs().max()) <= 1e-7 and float(Ax.min()) >= -1e-6 and float(Ax.max()) <= 1 + 1e-6
+    g = dq.H @ xd + dq.q
+    scale = max(1.0, float(g.abs().max()))
+    assert float((g + dq.A.t() @ y - zl + zu).abs().max()) <= 1e-6 * scale
+    assert float(zl.min()) >= -1e-8 and float(zu.min()) >= -1e-8
+    assert float((zl * xd).abs().max()) <= 1e-6 * scale and float((zu * (1 - xd)).abs().max()) <= 1e-6 * scale
+    yi, Ai = y[neq:], Ax[neq:]
+    assert float((yi.clamp(min=0) * (1 - Ai)).abs().max()) <= 1e-6 * scale
+    assert float((yi.clamp(max=0) * Ai).abs().max()) <= 1e-6 * scale
+    s.close()
