@@ -260,7 +260,8 @@ int32_t madqp_kkt_matrix(madqp_kkt* kkt, double** K, int64_t* ld);
  * src/KKT/normalkkt.jl:51-101): A in CSR (a_*: m rows) and A' in CSR (at_*: nx rows = the CSC of A), device
  * int64 / double arrays, column indices ascending within a row, borrowed.  mode 0: condensed
  * K = H + Sigma_x + A' Theta A (H dense or NULL); mode 1: normal equations A Sigma^-1 A' (LP only,
- * assemble_normal_system! src/utils.jl:266-298).  The factorised matrix stays dense; every madqp_kkt_*
+ * assemble_normal_system! src/utils.jl:266-298); mode 2: the augmented system of madqp_kkt_create_augmented
+ * (the CSR entries are scattered into its constraint rows).  The factorised matrix stays dense; every madqp_kkt_*
  * call works on the returned object (products with A / A' become CSR mat-vecs). */
 int32_t madqp_kkt_create_sparse(madqp_ctx* ctx, int32_t mode, int64_t nx, int64_t m, int64_t ns,
                                 const int64_t* ind_ineq_host, const double* H, int64_t ldh, const int64_t* a_ptr,

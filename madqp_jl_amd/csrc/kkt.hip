@@ -78,6 +78,12 @@ __global__ __launch_bounds__(256) void aug_fill_kernel(int64_t nx, int64_t np, i
     const int64_t i0 = ti * 64, j0 = tj * 64, N = np + m;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     __shared__ double tile[64][65];
+    if (i0 >= np && j0 < np && !A) {  // sparse Jacobian: zero here, aug_scatter_kernel adds the entries
+        const int64_t i = i0 + tx;
+        if (i < N)
+            for (int c = ty; c < 64; c += 4) K[i + (j0 + c) * ldk] = 0.0;
+        return;
+    }
     if (i0 >= np && j0 < np) {  // constraint rows x variable columns
         const int64_t r0 = i0 - np;
         for (int rr = ty; rr < 64; rr += 4) {
@@ -104,6 +110,16 @@ __global__ __launch_bounds__(256) void aug_fill_kernel(int64_t nx, int64_t np, i
         }
         K[i + j * ldk] = v;
     }
+}
+
+// sparse Jacobian (CSR of A): K[np + r, col] = val, 16 lanes per row
+__global__ __launch_bounds__(256) void aug_scatter_kernel(int64_t m, int64_t np, const int64_t* __restrict__ ptr,
+                                                          const int64_t* __restrict__ col,
+                                                          const double* __restrict__ val, double* __restrict__ K,
+                                                          int64_t ldk) {
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    if (r >= m) return;
+    for (int64_t e = ptr[r] + (threadIdx.x & 15); e < ptr[r + 1]; e += 16) K[(np + r) + col[e] * ldk] = val[e];
 }
 }  // namespace
 
@@ -224,15 +240,17 @@ extern "C" int32_t madqp_kkt_create(madqp_ctx* ctx, int64_t nx, int64_t m, int64
 
 // Sparse front end: A as CSR (a_*: m rows, column indices < nx, ascending within a row) and A' as CSR
 // (at_*: nx rows, indices < m), both device, int64, borrowed.  mode 0: condensed K = H + Sigma_x + A' Theta A
-// (H dense or NULL), mode 1: the reference's normal equations A Sigma^-1 A' (LP only).
+// (H dense or NULL), mode 1: the reference's normal equations A Sigma^-1 A' (LP only), mode 2: the augmented
+// system [H + Sigma_x, A'; A, -D] (H dense, NULL or diagonal through madqp_kkt_set_hdiag).
 extern "C" int32_t madqp_kkt_create_sparse(madqp_ctx* ctx, int32_t mode, int64_t nx, int64_t m, int64_t ns,
                                            const int64_t* ind_ineq_host, const double* H, int64_t ldh,
                                            const int64_t* a_ptr, const int64_t* a_col, const double* a_val,
                                            const int64_t* at_ptr, const int64_t* at_col, const double* at_val,
                                            madqp_kkt** out) {
     if (!ctx) return MADQP_ERR_ARG;
-    ARG_TRY(ctx, (mode == 0 || mode == 1) && a_ptr && at_ptr && (!H || ldh >= nx) && !(mode == 1 && H));
-    int32_t r = kkt_create_common(ctx, mode == 1 ? KKT_NORMAL : KKT_CONDENSED, nx, m, ns, ind_ineq_host, H, ldh,
+    ARG_TRY(ctx, (mode >= 0 && mode <= 2) && a_ptr && at_ptr && (!H || ldh >= nx) && !(mode == 1 && H));
+    int32_t r = kkt_create_common(ctx, mode == 1 ? KKT_NORMAL : mode == 2 ? KKT_AUGMENTED : KKT_CONDENSED, nx, m, ns,
+                                  ind_ineq_host, H, ldh,
                                   nullptr, 0, nullptr, 0, out);
     if (r) return r;
     madqp_kkt* k = *out;
@@ -325,6 +343,11 @@ static int32_t kkt_build_impl(madqp_kkt* k, const madqp_state* st, int64_t nrang
         hipLaunchKernelGGL(aug_fill_kernel, dim3(tiles, tiles), dim3(256), 0, ctx->stream, k->nx, k->np, k->m, k->H,
                            k->ldh, k->hdiag, st->pr_diag, k->A, k->lda, k->theta, k->K, k->ldk);
         LAUNCH_CHECK(ctx);
+        if (k->a_ptr && k->m) {
+            hipLaunchKernelGGL(aug_scatter_kernel, dim3((unsigned)((k->m * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               k->m, k->np, k->a_ptr, k->a_col, k->a_val, k->K, k->ldk);
+            LAUNCH_CHECK(ctx);
+        }
         return MADQP_OK;
     }
     {

@@ -228,3 +228,14 @@ class HIPSparseNormalKKTSystem(_SparseMixin, HIPNormalKKTSystem):
             raise ValueError("The KKT system NormalKKTSystem supports only linear programs "
                              "(or a diagonal Hessian given as a vector).")  # normalkkt.jl:45-48
         self._init_sparse(backend, st, nx, ind_ineq, H, csr, 1)
+
+
+class HIPSparseAugmentedKKTSystem(_SparseMixin, HIPAugmentedKKTSystem):
+    """Augmented system with a sparse Jacobian (``DeviceCSR``) scattered into the dense quasi-definite matrix:
+    the exact treatment of equality rows for a QP whose Hessian is dense (or diagonal, 1-D tensor)."""
+
+    def __init__(self, backend, st, nx, ind_ineq, H, csr):
+        if H is not None and H.dim() == 2:
+            assert H.is_contiguous() and H.shape == (nx, nx)
+        self._init_sparse(backend, st, nx, ind_ineq, H, csr, 2)
+        self.linear_solver = HIPQuasiDefiniteSolver(backend, self._h, self.nx, self.m)

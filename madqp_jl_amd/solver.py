@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from ._lib import CMpcInfo, CMpcOptions
-from .kkt import (HIPAugmentedKKTSystem, HIPCondensedKKTSystem, HIPNormalKKTSystem,
+from .kkt import (HIPAugmentedKKTSystem, HIPCondensedKKTSystem, HIPNormalKKTSystem, HIPSparseAugmentedKKTSystem,
                   HIPSparseCondensedKKTSystem, HIPSparseNormalKKTSystem)
 from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, FixedRegularization,
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
@@ -105,8 +105,8 @@ class MPCSolver:
         if diag_h and not isinstance(qp.A, DeviceCSR) and self.opt.kkt_system != "augmented":
             raise ValueError("a diagonal Hessian (1-D tensor) needs the sparse front end (A as DeviceCSR) "
                              "or kkt_system='augmented'")
-        if self.opt.kkt_system == "augmented" and (isinstance(qp.A, DeviceCSR) or self.opt.distributed):
-            raise ValueError("the augmented KKT system takes a dense Jacobian on one GPU")
+        if self.opt.kkt_system == "augmented" and self.opt.distributed:
+            raise ValueError("the augmented KKT system is factorised on one GPU")
         if self.opt.kkt_system == "normal" and qp.H is not None and not diag_h:
             raise ValueError("The KKT system NormalKKTSystem supports only linear programs.")
         if self.opt.kkt_system == "condensed" and len(self.ind_eq) and (
@@ -351,7 +351,8 @@ class MPCSolver:
         if isinstance(self.A, DeviceCSR):  # sparse front end: dense K / Cholesky, CSR products
             if opt.distributed:
                 raise ValueError("the sparse front end runs on one GPU")
-            cls = HIPSparseNormalKKTSystem if opt.kkt_system == "normal" else HIPSparseCondensedKKTSystem
+            cls = {"normal": HIPSparseNormalKKTSystem, "augmented": HIPSparseAugmentedKKTSystem,
+                   "condensed": HIPSparseCondensedKKTSystem}[opt.kkt_system]
             self.kkt = cls(be, st, nx, self.ind_ineq, self.H, self.A)
         elif opt.kkt_system == "augmented":
             self.kkt = HIPAugmentedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)

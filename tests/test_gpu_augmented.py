@@ -137,12 +137,29 @@ def test_augmented_equals_condensed(hip):
     assert np.max(np.abs(ra["multipliers"] - rc["multipliers"])) < 1e-5
 
 
-def test_augmented_rejects_what_it_cannot_take(hip):
-    qp = Q.synthetic_qp(3, 30, 10)
-    dq = M.DeviceQP.from_numpy(hip.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0,
-                               sparse=True)
-    with pytest.raises(ValueError):
-        M.MPCSolver(dq, hip, kkt_system="augmented")
+@pytest.mark.parametrize("diag_h", [False, True])
+def test_augmented_sparse_jacobian(hip, diag_h):
+    """The same augmented matrix from a CSR Jacobian (entries scattered into the constraint rows): identical
+    iterates to the dense-Jacobian object, equality rows and the default regularization included."""
+    qp = Q.sparse_qp(11, 120, 50, per_row=5, equality_cons=(4, 9, 30))
+    if diag_h:
+        qp.H = np.diag(np.diag(qp.H))
+    args = (qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
+    res = []
+    for sparse in (False, True):
+        dq = M.DeviceQP.from_numpy(hip.device, qp.H, *args, sparse=sparse)
+        if diag_h:
+            dq.H = torch.as_tensor(np.diag(qp.H).copy(), device=hip.device)
+        s = M.MPCSolver(dq, hip, kkt_system="augmented")
+        res.append(s.solve())
+        assert type(s.kkt).__name__ == ("HIPSparseAugmentedKKTSystem" if sparse else "HIPAugmentedKKTSystem")
+        s.close()
+    rd, rs = res
+    assert rd["status"] == rs["status"] == M.SOLVE_SUCCEEDED and rd["iter"] == rs["iter"]
+    compare_traces(rs["trace"], rd["trace"], "sparse vs dense Jacobian")
+    assert np.max(np.abs(rd["solution"] - rs["solution"])) <= 1e-9
+    ref = mpc.solve(qp, kkt_system="K2")
+    assert ref["iter"] == rs["iter"] and np.max(np.abs(ref["solution"] - rs["solution"])) <= 1e-7
 
 
 def test_augmented_full_size_n5k_with_equalities(hip):
