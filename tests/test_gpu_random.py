@@ -42,6 +42,12 @@ def test_random_patterns_all_drivers(hip, seed, n, m, lp):
     b = M.BatchedMPCSolver([to_device(qp, hip)], hip, regularization=REG)
     same(b.solve()[0], ref, "batched engine, B = 1")
     b.close()
+    # MadNLP's default formulation (K2) with the reference's default regularization, dense and CSR Jacobian
+    kref = mpc.solve(qp, kkt_system="K2")
+    for sparse in ((False, True) if m and n > 1 else (False,)):
+        s = M.MPCSolver(to_device(qp, hip, sparse=sparse), hip, kkt_system="augmented", driver="native")
+        same(s.solve(), kref, f"augmented system, sparse={sparse}")
+        s.close()
     if lp:  # the reference's own formulation (normal equations, delta_d = 0), dense and CSR Jacobian
         nref = mpc.solve(qp, kkt_system="normal", regularization=mpc.FixedRegularization(1e-8, 0.0))
         for sparse in (False, True):

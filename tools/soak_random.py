@@ -15,9 +15,10 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--count", type=int, default=100)
     p.add_argument("--seed0", type=int, default=1000)
-    p.add_argument("--mode", choices=("drivers", "sparse"), default="drivers",
+    p.add_argument("--mode", choices=("drivers", "sparse", "augmented"), default="drivers",
                    help="drivers: python / native / batched on dense data; sparse: CSR front end, condensed and (LPs) "
-                        "normal equations, against the dense path's oracle")
+                        "normal equations, against the dense path's oracle; augmented: the K2 system (dense and CSR Jacobian) with "
+                        "the reference's default regularization against the oracle's K2 path")
     a = p.parse_args()
     import madqp_jl_amd as M
     from oracle import mpc
@@ -50,6 +51,14 @@ def main():
             ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG)
             ds = M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0, sparse=True)
             cands = [("sparse-condensed", lambda: M.MPCSolver(ds, be, regularization=REG, driver="native"))]
+        elif a.mode == "augmented":
+            ref = mpc.solve(qp, kkt_system="K2")
+            cands = [("augmented-python", lambda: M.MPCSolver(dq, be, kkt_system="augmented")),
+                     ("augmented-native", lambda: M.MPCSolver(dq, be, kkt_system="augmented", driver="native"))]
+            if m > 0:
+                ds = M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0,
+                                           qp.c0, sparse=True)
+                cands.append(("augmented-csr", lambda: M.MPCSolver(ds, be, kkt_system="augmented", driver="native")))
         else:
             cands = [("python", lambda: M.MPCSolver(dq, be, regularization=REG)),
                      ("native", lambda: M.MPCSolver(dq, be, regularization=REG, driver="native")),
