@@ -14,7 +14,12 @@ call ``MPCSolver`` (scripts/benchmarks_cpu.jl:17-31, scripts/common.jl):
 * :func:`to_device` -- hands the result to the sparse front end (``DeviceCSR``);
 * :func:`benchmark_row` -- the nine columns the scripts record (scripts/benchmarks_cpu.jl:47-55).
 
-Not covered: ``presolve_qp`` (it delegates to ``QuadraticModels.presolve``, an external package).
+* :func:`presolve` -- ``presolve_qp`` (scripts/common.jl:102-126) delegates to ``QuadraticModels.presolve``, an
+  un-vendored package (compat ``QuadraticModels`` in scripts/Project.toml); its documented basic reductions are
+  restated here -- fixed variables, empty rows, singleton rows, unconstrained linear variables, rows made redundant
+  by the variable bounds -- with the postsolve that maps a primal-dual solution back.  Same contract as the script
+  uses: a reduced model and a flag, ``False`` when presolve alone settles the instance (solved, infeasible or
+  unbounded).
 """
 from __future__ import annotations
 
@@ -222,6 +227,179 @@ def read_qps(source) -> HostQP:
     if sense_max:
         c, H, c0 = -c, -H, -c0
     return HostQP(c0, c, H, A, lvar, uvar, lcon, ucon, name=name, varnames=varnames, connames=connames)
+
+
+# -------------------------------------------------------------------------------------------- presolve
+@dataclass
+class Presolved:
+    """Outcome of :func:`presolve`.  ``flag`` as in ``presolve_qp`` (scripts/common.jl:109-126): True = ``qp`` is the
+    reduced model to solve; False = nothing left to solve (``status``: "solved", "infeasible" or "unbounded")."""
+
+    qp: HostQP
+    flag: bool
+    status: str  # "reduced" | "unchanged" | "solved" | "infeasible" | "unbounded"
+    original: HostQP
+    keep_var: np.ndarray
+    keep_con: np.ndarray
+    x_removed: np.ndarray  # full length; values of the eliminated variables
+    ops: list  # the reductions in the order they were applied; the postsolve undoes them in reverse
+
+    def postsolve(self, x=None, y=None, zl=None, zu=None):
+        """Solution of the reduced model -> primal-dual point of the ORIGINAL model (stationarity convention of the
+        solver: H x + c + A'y - zl + zu = 0).  With status "solved" call it without arguments."""
+        o = self.original
+        n, m = o.nvar, o.ncon
+        xf = self.x_removed.copy()
+        yf, zlf, zuf = np.zeros(m), np.zeros(n), np.zeros(n)
+        if len(self.keep_var):
+            xf[self.keep_var] = x
+        if y is not None and len(self.keep_con):
+            yf[self.keep_con] = y
+        if zl is not None and zu is not None:
+            zlf[self.keep_var], zuf[self.keep_var] = zl, zu
+            At = o.A.tocsc()
+            g = o.H @ xf + o.c  # gradient of the objective at the (complete) primal point
+            for op in reversed(self.ops):
+                if op[0] == "var":  # eliminated variable: the reduced cost goes to whichever bound holds it
+                    jv = op[1]
+                    col = At.getcol(jv)
+                    r = g[jv] + col.data @ yf[col.indices]
+                    zlf[jv], zuf[jv] = max(r, 0.0), max(-r, 0.0)
+                elif op[0] == "singleton":  # a bound that came from this row: its multiplier belongs to the row
+                    _, iv, jv, a, set_lo, set_hi = op  # (a y_i = -zl_j for the lower, a y_i = zu_j for the upper bound)
+                    if set_lo:
+                        yf[iv] -= zlf[jv] / a
+                        zlf[jv] = 0.0
+                    if set_hi:
+                        yf[iv] += zuf[jv] / a
+                        zuf[jv] = 0.0
+        obj = o.c0 + o.c @ xf + 0.5 * xf @ (o.H @ xf)
+        return dict(x=xf, y=yf, zl=zlf, zu=zuf, objective=float(obj))
+
+
+def presolve(qp: HostQP, feas_tol: float = 1e-9, max_pass: int = 50) -> Presolved:
+    """Basic presolve (the reductions ``QuadraticModels.presolve`` documents), repeated until nothing changes:
+
+    1. fixed variables (lvar == uvar) are substituted out;
+    2. empty rows are checked (lcon <= 0 <= ucon) and dropped;
+    3. singleton rows ``l <= a x_j <= u`` become bounds on x_j;
+    4. variables that appear in no row and no quadratic term go to the bound their cost points at;
+    5. rows whose activity range implied by the variable bounds lies inside [lcon, ucon] are dropped.
+    """
+    n, m = qp.nvar, qp.ncon
+    A, At, H = qp.A.tocsr(), qp.A.tocsc(), qp.H.tocsr()
+    lvar, uvar, lcon, ucon = (np.array(v, dtype=np.float64) for v in (qp.lvar, qp.uvar, qp.lcon, qp.ucon))
+    c, c0 = np.array(qp.c, dtype=np.float64), float(qp.c0)
+    av, ac = np.ones(n, dtype=bool), np.ones(m, dtype=bool)
+    xr = np.zeros(n)
+    ops = []
+    pat, patH = sp.csr_matrix((np.ones(A.nnz), A.indices, A.indptr), shape=A.shape), H.copy()
+    patH.data = np.ones(H.nnz)
+    status = None
+
+    def remove_var(j, v):
+        nonlocal c0
+        xr[j] = v
+        hj = H.getrow(j)
+        c0 += c[j] * v + 0.5 * H[j, j] * v * v
+        c[hj.indices] += hj.data * v  # H symmetric: column j = row j (c[j] itself is no longer used)
+        col = At.getcol(j)
+        lcon[col.indices] -= col.data * v
+        ucon[col.indices] -= col.data * v
+        av[j] = False
+        ops.append(("var", int(j)))
+
+    for _ in range(max_pass):
+        changed = False
+        if np.any(av & (lvar > uvar + feas_tol * np.maximum(1.0, np.abs(lvar)))):
+            status = "infeasible"
+            break
+        for j in np.flatnonzero(av & (lvar >= uvar)):  # 1. fixed (also after a singleton row closed the interval)
+            remove_var(j, lvar[j])
+            changed = True
+        rcount = np.asarray(pat @ av.astype(np.float64)).ravel()
+        for i in np.flatnonzero(ac & (rcount == 0)):  # 2. empty rows
+            if lcon[i] > feas_tol * max(1.0, abs(lcon[i])) or ucon[i] < -feas_tol * max(1.0, abs(ucon[i])):
+                status = "infeasible"
+                break
+            ac[i] = False
+            changed = True
+        if status:
+            break
+        for i in np.flatnonzero(ac & (rcount == 1)):  # 3. singleton rows
+            row = A.getrow(i)
+            k = np.flatnonzero(av[row.indices])
+            if len(k) != 1 or row.data[k[0]] == 0.0:
+                continue
+            j, a = int(row.indices[k[0]]), float(row.data[k[0]])
+            lo, hi = (lcon[i] / a, ucon[i] / a) if a > 0 else (ucon[i] / a, lcon[i] / a)
+            set_lo, set_hi = bool(lo > lvar[j]), bool(hi < uvar[j])
+            if set_lo:
+                lvar[j] = lo
+            if set_hi:
+                uvar[j] = hi
+            ops.append(("singleton", int(i), j, a, set_lo, set_hi))
+            ac[i] = False
+            changed = True
+        ccount = np.asarray(pat.T @ ac.astype(np.float64)).ravel()
+        hcount = np.asarray(patH @ av.astype(np.float64)).ravel()
+        for j in np.flatnonzero(av & (ccount == 0) & (hcount == 0)):  # 4. unconstrained linear variables
+            if lvar[j] > uvar[j]:
+                continue  # caught as infeasible at the top of the next pass
+            if c[j] > 0.0:
+                v = lvar[j]
+            elif c[j] < 0.0:
+                v = uvar[j]
+            else:
+                v = lvar[j] if np.isfinite(lvar[j]) else (uvar[j] if np.isfinite(uvar[j]) else 0.0)
+            if not np.isfinite(v):
+                status = "unbounded"
+                break
+            remove_var(j, v)
+            changed = True
+        if status:
+            break
+        # 5. redundant rows: activity range over the box of the active variables
+        if np.any(ac) and np.any(av):
+            Aa = A.multiply(av.astype(np.float64)[None, :]).tocsr()
+            pos, neg = Aa.maximum(0), Aa.minimum(0)
+            with np.errstate(invalid="ignore"):
+                lo_b, hi_b = np.where(av, lvar, 0.0), np.where(av, uvar, 0.0)
+                amin = _bound_dot(pos, lo_b) + _bound_dot(neg, hi_b)
+                amax = _bound_dot(pos, hi_b) + _bound_dot(neg, lo_b)
+            tol = feas_tol * np.maximum(1.0, np.maximum(np.abs(lcon), np.abs(ucon)))
+            tol[~np.isfinite(tol)] = feas_tol
+            if np.any(ac & ((amin > ucon + tol) | (amax < lcon - tol))):
+                status = "infeasible"
+                break
+            red = ac & (rcount > 1) & (amin >= lcon) & (amax <= ucon) & (lcon < ucon)
+            if np.any(red):
+                ac[red] = False
+                changed = True
+        if not changed:
+            break
+    kv, kc = np.flatnonzero(av), np.flatnonzero(ac)
+    if status in ("infeasible", "unbounded"):
+        return Presolved(qp, False, status, qp, np.arange(n), np.arange(m), xr, [])
+    if len(kv) == 0:
+        return Presolved(qp, False, "solved", qp, kv, kc[:0], xr, ops)
+    if len(kv) == n and len(kc) == m:
+        return Presolved(qp, True, "unchanged", qp, kv, kc, xr, [])
+    names = lambda lst, idx: [lst[i] for i in idx] if lst else []
+    red = HostQP(c0, c[kv], H[kv][:, kv], A[kc][:, kv], lvar[kv], uvar[kv], lcon[kc], ucon[kc], x0=qp.x0[kv],
+                 y0=qp.y0[kc], name=qp.name + "-ps", varnames=names(qp.varnames, kv), connames=names(qp.connames, kc))
+    return Presolved(red, True, "reduced", qp, kv, kc, xr, ops)
+
+
+def _bound_dot(M, b):
+    """M @ b for a sign-definite sparse M and bounds b that may be infinite (0 * inf = 0)."""
+    fin = np.where(np.isfinite(b), b, 0.0)
+    out = np.asarray(M @ fin).ravel()
+    inf_hit = np.asarray(abs(M) @ (~np.isfinite(b)).astype(np.float64)).ravel() > 0
+    if np.any(inf_hit):
+        sgn = np.asarray(M @ np.where(np.isfinite(b), 0.0, np.sign(b))).ravel()
+        out = np.where(inf_hit, np.where(sgn > 0, np.inf, -np.inf), out)
+    return out
 
 
 # --------------------------------------------------------------------------------------------- scaling

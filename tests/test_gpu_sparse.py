@@ -143,6 +143,29 @@ def test_instance_file_to_gpu_pipeline(hip):
     assert np.max(np.abs(r["solution"][:40] - ref["solution"])) < 1e-5
 
 
+@pytest.mark.parametrize("seed,lp", [(0, False), (2, True)])
+def test_presolve_scale_solve_postsolve_on_device(hip, seed, lp):
+    """presolve_qp -> scale_qp -> MPCSolver (scripts/benchmarks_cpu.jl:27-45) with the device solver in the middle,
+    then back: unscale, postsolve, and check the optimality conditions of the ORIGINAL model (multipliers of the
+    rows the presolve removed included).  Augmented system: the model has equality rows, default regularization."""
+    from madqp_jl_amd import preprocess as P
+    from tests.test_preprocess import kkt_violation, planted_qp
+
+    qp = planted_qp(seed, lp)
+    ps = P.presolve(qp)
+    assert ps.flag
+    scaled, Dr, Dc = P.ruiz_scale(ps.qp)
+    s = M.MPCSolver(P.to_device(scaled, hip), hip, kkt_system="augmented", tol=1e-9, driver="native")
+    r = s.solve()
+    s.close()
+    assert r["status"] == M.SOLVE_SUCCEEDED
+    # scale_qp: xs = Dc x, rows divided by Dr  =>  x = xs / Dc, y = ys / Dr, z = zs * Dc
+    full = ps.postsolve(r["solution"] / Dc, r["multipliers"] / Dr, r["multipliers_L"] * Dc, r["multipliers_U"] * Dc)
+    assert abs(full["objective"] - r["objective"]) <= 1e-8 * max(1.0, abs(r["objective"]))
+    assert kkt_violation(qp, full) <= 2e-6
+    assert len(full["x"]) == qp.nvar > ps.qp.nvar and len(full["y"]) == qp.ncon > ps.qp.ncon
+
+
 @pytest.mark.parametrize("N,ksys", [(12, "normal"), (25, "normal"), (12, "condensed")])
 def test_boundary_control_qp_diagonal_hessian(hip, N, ksys):
     """CONT-type QP (BASELINE configs[2] stand-in): sparse equality rows, diagonal Hessian kept as a vector.

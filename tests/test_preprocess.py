@@ -184,3 +184,119 @@ def test_benchmark_row():
     qp = P.read_qps(HS21_QPS)
     row = P.benchmark_row(qp, dict(status=1, iter=7, objective=-99.96), 0.5, 0.25)
     assert row == (2, 1, 2, 2, 1, 7, -99.96, 0.5, 0.25)
+
+
+# ------------------------------------------------------------------------------------------------ presolve
+def kkt_violation(qp, s):
+    """Largest violation of the optimality conditions of ``qp`` at the primal-dual point ``s`` (x, y, zl, zu):
+    stationarity H x + c + A'y - zl + zu = 0, feasibility, signs, complementarity -- no solver involved."""
+    x, y, zl, zu = s["x"], s["y"], s["zl"], s["zu"]
+    Ax = qp.A @ x
+    v = [np.max(np.abs(qp.H @ x + qp.c + qp.A.T @ y - zl + zu), initial=0.0),
+         np.max(np.maximum(qp.lvar - x, 0), initial=0.0), np.max(np.maximum(x - qp.uvar, 0), initial=0.0),
+         np.max(np.maximum(qp.lcon - Ax, 0), initial=0.0), np.max(np.maximum(Ax - qp.ucon, 0), initial=0.0),
+         np.max(np.maximum(-zl, 0), initial=0.0), np.max(np.maximum(-zu, 0), initial=0.0)]
+    fin = lambda b, d: np.where(np.isfinite(b), d, 0.0)
+    v += [np.max(np.abs(zl * fin(qp.lvar, x - qp.lvar)), initial=0.0), np.max(np.abs(zu * fin(qp.uvar, qp.uvar - x)), initial=0.0),
+          np.max(np.abs(np.where(np.isfinite(qp.lvar), 0.0, zl)), initial=0.0),
+          np.max(np.abs(np.where(np.isfinite(qp.uvar), 0.0, zu)), initial=0.0),
+          np.max(np.abs(np.maximum(y, 0) * fin(qp.ucon, qp.ucon - Ax)), initial=0.0),  # y > 0: upper side active
+          np.max(np.abs(np.minimum(y, 0) * fin(qp.lcon, Ax - qp.lcon)), initial=0.0),
+          np.max(np.abs(np.where(np.isfinite(qp.ucon), 0.0, np.maximum(y, 0))), initial=0.0),
+          np.max(np.abs(np.where(np.isfinite(qp.lcon), 0.0, np.minimum(y, 0))), initial=0.0)]
+    return max(v)
+
+
+def planted_qp(seed, lp=False):
+    """A random sparse QP with every structure the presolve removes planted into it."""
+    rng = np.random.default_rng(seed)
+    n, m = 30, 22
+    A = sp.random(m, n, density=0.25, random_state=rng, data_rvs=rng.standard_normal).tolil()
+    R = sp.random(n, n, density=0.1, random_state=rng, data_rvs=rng.standard_normal)
+    H = (R @ R.T + sp.identity(n)).tolil() if not lp else sp.lil_matrix((n, n))
+    c = rng.standard_normal(n)
+    lvar, uvar = -1.0 - rng.random(n), 1.0 + rng.random(n)
+    xf = rng.uniform(-0.5, 0.5, n)  # a strictly feasible point for the rows
+    fixed, free_cols = [2, 11, 19], [5, 23]
+    lvar[fixed] = uvar[fixed] = xf[fixed]
+    for j in free_cols:  # variables in no row and no quadratic term
+        A[:, j] = 0.0
+        H[j, :] = 0.0
+        H[:, j] = 0.0
+    c[5], c[23] = 0.7, -0.4
+    lvar[7] = -np.inf  # a one-sided variable
+    empty, single, single_eq, single_neg, redundant = [3, 14], 6, 9, 17, 20
+    for i in empty:
+        A[i, :] = 0.0
+    A[redundant, 7] = 0.0  # keep the redundant row's activity range finite
+    for i, j, a in ((single, 8, 2.0), (single_eq, 12, -1.5), (single_neg, 21, -0.5)):
+        A[i, :] = 0.0
+        A[i, j] = a
+    A = A.tocsr()
+    Ax = A @ xf
+    lcon, ucon = Ax - 0.3 - rng.random(m), Ax + 0.3 + rng.random(m)
+    eq = [0, 10]
+    lcon[eq] = ucon[eq] = Ax[eq]
+    lcon[empty], ucon[empty] = [-1.0, 0.0], [0.0, np.inf]
+    lcon[single], ucon[single] = 2.0 * (xf[8] - 0.05), np.inf  # tightens the lower bound of x8 (likely active)
+    lcon[single_eq] = ucon[single_eq] = -1.5 * xf[12]  # fixes x12 through a row
+    lcon[single_neg], ucon[single_neg] = -np.inf, -0.5 * (xf[21] - 0.02)  # a < 0: an upper row bound -> lower bound
+    lcon[redundant], ucon[redundant] = -1e3, 1e3
+    c[8], c[21] = 3.0, 3.0  # push x8, x21 against the bounds the singleton rows created
+    return P.HostQP(0.25, c, sp.csr_matrix(H), A, lvar, uvar, lcon, ucon, name=f"planted{seed}")
+
+
+@pytest.mark.parametrize("seed,lp", [(0, False), (1, False), (2, True), (3, True)])
+def test_presolve_reductions_and_postsolve(seed, lp):
+    qp = planted_qp(seed, lp)
+    ps = P.presolve(qp)
+    assert ps.flag and ps.status == "reduced"
+    gone_v, gone_c = set(range(qp.nvar)) - set(ps.keep_var), set(range(qp.ncon)) - set(ps.keep_con)
+    assert {2, 11, 19, 5, 23, 12} <= gone_v  # fixed, unconstrained linear, fixed by a singleton equality row
+    assert {3, 14, 6, 9, 17, 20} <= gone_c  # empty, singleton, redundant rows
+    assert ps.qp.nvar == qp.nvar - len(gone_v) and ps.qp.ncon == qp.ncon - len(gone_c)
+    assert ps.x_removed[5] == qp.lvar[5] and ps.x_removed[23] == qp.uvar[23]  # cost sign picks the bound
+    r = mpc.solve(dense(ps.qp), kkt_system="K2", tol=1e-9)
+    assert r["status"] == mpc.SOLVE_SUCCEEDED
+    full = ps.postsolve(r["solution"], r["multipliers"], r["multipliers_L"], r["multipliers_U"])
+    assert abs(full["objective"] - r["objective"]) <= 1e-8 * max(1.0, abs(r["objective"]))  # c0 bookkeeping
+    assert kkt_violation(qp, full) <= 2e-6  # optimal for the ORIGINAL model, duals of the removed rows included
+    assert abs(full["y"][6]) > 1e-3 or abs(full["y"][17]) > 1e-3  # a singleton row's multiplier was recovered
+    if lp:
+        from scipy.optimize import linprog
+
+        cons = sp.vstack([qp.A, -qp.A]).tocsr()
+        rhs = np.concatenate([qp.ucon, -qp.lcon])
+        ok = np.isfinite(rhs)
+        lp_ref = linprog(qp.c, A_ub=cons[ok], b_ub=rhs[ok], bounds=list(zip(qp.lvar, qp.uvar)), method="highs")
+        assert lp_ref.status == 0 and abs(lp_ref.fun + qp.c0 - full["objective"]) <= 1e-6
+    ps2 = P.presolve(ps.qp)  # idempotent
+    assert ps2.status == "unchanged" and ps2.qp is ps.qp
+
+
+def test_presolve_flags():
+    """The three ways presolve_qp returns flag = false (scripts/common.jl:121-124): solved, infeasible, unbounded."""
+    z = lambda r, c: sp.csr_matrix((r, c))
+    inf = np.inf
+    # everything eliminated: x0 fixed, x1 unconstrained linear, the row a singleton turned into a bound
+    qp = P.HostQP(1.0, np.array([2.0, -1.0]), z(2, 2), sp.csr_matrix([[0.0, 1.0]]), np.array([3.0, 0.0]),
+                  np.array([3.0, inf]), np.array([-inf]), np.array([4.0]))
+    ps = P.presolve(qp)
+    assert not ps.flag and ps.status == "solved"
+    full = ps.postsolve()
+    assert np.allclose(full["x"], [3.0, 4.0]) and full["objective"] == pytest.approx(1.0 + 6.0 - 4.0)
+    # an empty row that cannot hold
+    qp = P.HostQP(0.0, np.ones(2), z(2, 2), z(1, 2), np.zeros(2), np.ones(2), np.array([1.0]), np.array([2.0]))
+    assert P.presolve(qp).status == "infeasible" and not P.presolve(qp).flag
+    # a singleton row against the variable's bounds
+    qp = P.HostQP(0.0, np.ones(1), z(1, 1), sp.csr_matrix([[1.0]]), np.zeros(1), np.ones(1), np.array([2.0]), np.array([3.0]))
+    assert P.presolve(qp).status == "infeasible"
+    # a free column whose cost pushes it to infinity
+    qp = P.HostQP(0.0, np.array([-1.0, 1.0]), z(2, 2), sp.csr_matrix([[0.0, 1.0]]), np.zeros(2), np.array([inf, 1.0]),
+                  np.array([0.0]), np.array([1.0]))
+    assert P.presolve(qp).status == "unbounded"
+    # nothing to do
+    qp = P.HostQP(0.0, np.ones(2), sp.identity(2), sp.csr_matrix([[1.0, 1.0]]), np.zeros(2), np.ones(2),
+                  np.array([0.5]), np.array([1.5]))
+    ps = P.presolve(qp)
+    assert ps.flag and ps.status == "unchanged" and ps.qp is qp
