@@ -229,6 +229,65 @@ def read_qps(source) -> HostQP:
     return HostQP(c0, c, H, A, lvar, uvar, lcon, ucon, name=name, varnames=varnames, connames=connames)
 
 
+def write_qps(qp: HostQP, path) -> None:
+    """Write the model as a free-format QPS file that :func:`read_qps` reads back exactly (values with ``repr``):
+    the inverse of the reader's conventions -- objective row first, ``RHS`` of the objective = -c0, ranged rows as
+    ``L`` + ``RANGES``, bounds relative to the MPS default 0 <= x < inf, ``QUADOBJ`` = upper triangle of H.
+    Rows without any finite bound are written as ``N`` rows (the reader drops those)."""
+    n, m = qp.nvar, qp.ncon
+    vn = qp.varnames if len(qp.varnames) == n else [f"X{j + 1}" for j in range(n)]
+    cn = qp.connames if len(qp.connames) == m else [f"R{i + 1}" for i in range(m)]
+    At = qp.A.tocsc()
+    f = lambda v: repr(float(v))
+    out = [f"NAME {qp.name.replace(' ', '_')}", "ROWS", " N OBJ"]
+    kind = []
+    for i in range(m):
+        lo, hi = qp.lcon[i], qp.ucon[i]
+        k = "E" if lo == hi else "N" if (lo == -np.inf and hi == np.inf) else "G" if hi == np.inf else "L"
+        kind.append(k)
+        out.append(f" {k} {cn[i]}")
+    out.append("COLUMNS")
+    for j in range(n):
+        out.append(f" {vn[j]} OBJ {f(qp.c[j])}")
+        col = At.getcol(j)
+        for i, v in zip(col.indices, col.data):
+            if v != 0.0:
+                out.append(f" {vn[j]} {cn[i]} {f(v)}")
+    out.append("RHS")
+    if qp.c0 != 0.0:
+        out.append(f" RHS OBJ {f(-qp.c0)}")
+    for i in range(m):
+        b = qp.lcon[i] if kind[i] in ("E", "G") else qp.ucon[i]
+        if kind[i] != "N" and b != 0.0:
+            out.append(f" RHS {cn[i]} {f(b)}")
+    rng = [i for i in range(m) if kind[i] == "L" and qp.lcon[i] > -np.inf]
+    if rng:
+        out.append("RANGES")
+        out += [f" RNG {cn[i]} {f(qp.ucon[i] - qp.lcon[i])}" for i in rng]
+    out.append("BOUNDS")
+    for j in range(n):
+        lo, hi = qp.lvar[j], qp.uvar[j]
+        if lo == -np.inf and hi == np.inf:
+            out.append(f" FR BND {vn[j]}")
+        elif lo == hi:
+            out.append(f" FX BND {vn[j]} {f(lo)}")
+        else:
+            if lo == -np.inf:
+                out.append(f" MI BND {vn[j]}")
+            elif lo != 0.0 or hi < 0.0:
+                out.append(f" LO BND {vn[j]} {f(lo)}")
+            if hi != np.inf:
+                out.append(f" UP BND {vn[j]} {f(hi)}")
+    Hu = sp.triu(qp.H).tocoo()
+    if Hu.nnz:
+        out.append("QUADOBJ")
+        out += [f" {vn[i]} {vn[j]} {f(v)}" for i, j, v in zip(Hu.row, Hu.col, Hu.data) if v != 0.0]
+    out.append("ENDATA")
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "wt") as fh:
+        fh.write("\n".join(out) + "\n")
+
+
 # -------------------------------------------------------------------------------------------- presolve
 @dataclass
 class Presolved:

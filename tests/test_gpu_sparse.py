@@ -2,6 +2,8 @@
 src/utils.jl:148-298, NormalKKTSystem constructor src/KKT/normalkkt.jl:51-101).  The Jacobian is CSR on
 the device, the factorised matrix stays dense: assembled matrix, products and whole solves must agree
 with the dense path of the same library and with the CPU oracle on the densified problem."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -196,3 +198,47 @@ def test_boundary_control_qp_diagonal_hessian(hip, N, ksys):
         for t, g in zip(r["trace"], ref["trace"]):
             for key in ("alpha_p", "alpha_d", "mu"):
                 assert close(t[key], g[key], 1e-6 if ksys == "normal" else 1e-4), (t["k"], key, t[key], g[key])
+
+
+def test_benchmark_loop_over_instance_files(hip, tmp_path):
+    """tools/run_benchmarks.py = the loop of scripts/benchmarks_cpu.jl:10-62 on instance files written here
+    (HS21 from its published statement, two planted models, one LP that the presolve settles alone, one file that
+    does not parse): nine numbers per solved instance, objective of the ORIGINAL model despite presolve + scaling."""
+    import sys as _sys
+
+    from madqp_jl_amd import preprocess as P
+    from tests.test_preprocess import HS21_QPS, dense, planted_qp
+
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_benchmarks
+
+    d = tmp_path / "inst"
+    d.mkdir()
+    (d / "hs21.qps").write_text(HS21_QPS)
+    models = {"hs21.qps": P.read_qps(HS21_QPS)}
+    for seed, lp in ((0, False), (3, True)):
+        qp = planted_qp(seed, lp)
+        P.write_qps(qp, str(d / f"planted{seed}.mps.gz"))
+        models[f"planted{seed}.mps.gz"] = qp
+    import scipy.sparse as sp
+
+    trivial = P.HostQP(1.0, np.array([2.0, -1.0]), sp.csr_matrix((2, 2)), sp.csr_matrix([[0.0, 1.0]]),
+                       np.array([3.0, 0.0]), np.array([3.0, np.inf]), np.array([-np.inf]), np.array([4.0]))
+    P.write_qps(trivial, str(d / "trivial.mps"))
+    (d / "broken.mps").write_text("NAME x\nNOSUCHSECTION\n")
+    out = str(tmp_path / "results.txt")
+    names, res = run_benchmarks.run(str(d), out=out, backend=hip, verbose=False)
+    assert names == sorted(["hs21.qps", "planted0.mps.gz", "planted3.mps.gz", "trivial.mps", "broken.mps"])
+    rows = dict(zip(names, res))
+    assert not rows["broken.mps"].any() and not rows["trivial.mps"].any()  # skipped: no row recorded
+    for name, qp in models.items():
+        row = rows[name]
+        # the oracle does not take fixed variables: its reference is the presolved model (same objective value,
+        # tests/test_preprocess.py checks that bookkeeping against the original model's optimality conditions)
+        ref = mpc.solve(dense(P.presolve(qp).qp), kkt_system="K2", tol=1e-9)
+        assert row[4] == M.SOLVE_SUCCEEDED and row[5] > 0 and row[7] > 0 and row[8] > 0
+        assert abs(row[6] - ref["objective"]) <= 1e-6 * max(1.0, abs(ref["objective"])), name
+        assert row[0] <= qp.nvar and row[1] <= qp.ncon  # presolved sizes
+    assert abs(rows["hs21.qps"][6] + 99.96) < 1e-6
+    lines = open(out).read().splitlines()
+    assert len(lines) == 5 and all(len(l.split("\t")) == 10 for l in lines)

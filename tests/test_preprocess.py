@@ -300,3 +300,22 @@ def test_presolve_flags():
                   np.array([0.5]), np.array([1.5]))
     ps = P.presolve(qp)
     assert ps.flag and ps.status == "unchanged" and ps.qp is qp
+
+
+def test_write_qps_round_trip(tmp_path):
+    """write_qps is the inverse of read_qps (values written with repr): every array comes back, ranged rows to
+    one rounding of ucon - (ucon - lcon); gz and plain."""
+    for seed, lp, ext in ((0, False, ".qps"), (3, True, ".mps.gz")):
+        qp = planted_qp(seed, lp)
+        path = str(tmp_path / f"inst{seed}{ext}")
+        P.write_qps(qp, path)
+        r = P.read_qps(path)
+        assert (r.nvar, r.ncon, r.c0) == (qp.nvar, qp.ncon, qp.c0)
+        assert abs(r.A - qp.A).max() == 0.0 and (abs(r.H - qp.H).max() if qp.H.nnz else 0.0) == 0.0
+        assert np.array_equal(r.c, qp.c) and np.array_equal(r.lvar, qp.lvar) and np.array_equal(r.uvar, qp.uvar)
+        assert np.array_equal(r.ucon, qp.ucon) and np.allclose(r.lcon, qp.lcon, rtol=0.0, atol=1e-15)
+    hs = P.read_qps(HS21_QPS)
+    P.write_qps(hs, str(tmp_path / "hs21.qps"))
+    back = P.read_qps(str(tmp_path / "hs21.qps"))
+    assert back.varnames == hs.varnames and back.connames == hs.connames and back.c0 == hs.c0
+    assert abs(back.H - hs.H).max() == 0.0 and np.array_equal(back.lcon, hs.lcon)
