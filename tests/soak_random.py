@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak: many random bound patterns / shapes through the per-problem drivers, the sparse front end and
-the batched engine, each against the CPU oracle.  python tools/soak_random.py --count 150"""
+the batched engine, each against the CPU oracle.  python tests/soak_random.py --count 150"""
 import argparse
 import os
 import sys
