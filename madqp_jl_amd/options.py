@@ -45,10 +45,10 @@ class IPMOptions:
         # "condensed" (HIPCondensedKKTSystem), "normal" (HIPNormalKKTSystem, LP) or "augmented" (HIPAugmentedKKTSystem:
         # the K2 form, equality rows without dual regularization)
         kkt_system="condensed",
-        # MadNLP.RelaxBound ("relax_bound": a fixed variable keeps both bounds, relaxed by bound_relax_factor like any
-        # other) is what the reference selects for condensed KKT systems, MakeParameter otherwise (src/utils.jl:81);
-        # elimination of fixed variables is not implemented: None = "relax_bound" for the condensed and augmented
-        # systems, "error" for the normal equations
+        # src/utils.jl:81: MadNLP.RelaxBound ("relax_bound": a fixed variable keeps both bounds, relaxed by
+        # bound_relax_factor like any other) for condensed KKT systems -- here the condensed and augmented systems --,
+        # MadNLP.MakeParameter ("make_parameter": fixed variables leave the problem, DeviceQP.eliminate_fixed) otherwise
+        # -- here the normal equations.  None = that rule; "error" refuses fixed variables.
         fixed_variable_treatment=None,
         distributed=False,  # True: assembly + Cholesky shared by the ranks of torch.distributed (dist.py)
         panel_width=None,  # block-column width of the distributed factorisation (multiple of 128)

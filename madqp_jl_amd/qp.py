@@ -101,6 +101,44 @@ class DeviceQP:
         An = DeviceCSR.from_dense(device, A2) if sparse else f(A2)
         return cls(Hn, f(q), An, f(lvar), f(uvar), f(lcon), f(ucon), f(x0), c0, f(y0), name)
 
+    def eliminate_fixed(self):
+        """``MadNLP.MakeParameter`` (the fixed-variable treatment src/utils.jl:81 selects for every KKT system that
+        is not condensed): variables with ``lvar == uvar`` leave the problem as parameters.  Returns None when there
+        are none, else ``(reduced DeviceQP, free, fixed, xfix, shift)`` with index tensors ``free`` / ``fixed``, the
+        fixed values and ``shift = A[:, fixed] xfix`` (the rows of the reduced model are ``A_f x_f`` in
+        ``[lcon - shift, ucon - shift]``).  All on the device."""
+        mask = self.lvar == self.uvar
+        if not bool(mask.any()):
+            return None
+        fixed, free = torch.nonzero(mask).flatten(), torch.nonzero(~mask).flatten()
+        xf = self.lvar[fixed]
+        c0 = self.c0 + float(self.q[fixed] @ xf)
+        q = self.q[free].clone()
+        H = self.H
+        if H is not None and H.dim() == 1:
+            c0 += 0.5 * float((H[fixed] * xf) @ xf)
+            H = H[free].contiguous()
+        elif H is not None:
+            Hx = H.index_select(1, fixed) @ xf  # H[:, fixed] xfix
+            c0 += 0.5 * float(Hx[fixed] @ xf)
+            q += Hx[free]
+            H = H.index_select(0, free).index_select(1, free).contiguous()
+        if isinstance(self.A, DeviceCSR):
+            a = self.A
+            isfix = mask[a.col]
+            shift = torch.zeros(self.ncon, dtype=torch.float64, device=self.q.device)
+            shift.index_add_(0, a.row[isfix], a.val[isfix] * self.lvar[a.col[isfix]])
+            newcol = torch.cumsum((~mask).to(torch.int64), 0) - 1
+            keep = ~isfix
+            A = DeviceCSR(self.q.device, self.ncon, free.numel(), a.row[keep].cpu().numpy(),
+                          newcol[a.col[keep]].cpu().numpy(), a.val[keep].cpu().numpy())
+        else:
+            shift = self.A.index_select(1, fixed) @ xf
+            A = self.A.index_select(1, free).contiguous()
+        red = DeviceQP(H, q, A, self.lvar[free].clone(), self.uvar[free].clone(), self.lcon - shift, self.ucon - shift,
+                       self.x0[free].clone(), c0, self.y0, self.name + "-free")
+        return red, free, fixed, xf, shift
+
     @classmethod
     def synthetic(cls, backend, seed: int, n: int, m: int, family: str = "wigner"):
         """0 <= x <= 1, 0 <= Ax <= 1, x0 = 0; A ~ N(0,1), H Wigner + 3 I (or LP)."""

@@ -37,14 +37,14 @@ class SolveException(Exception):
 def get_index_constraints(lvar, uvar, lcon, ucon, fixed_variable_treatment="error"):
     """MadNLP.get_index_constraints as called at src/structure.jl:95-102 (host, numpy); EnforceEquality.
     Fixed variables (lvar == uvar): "relax_bound" = MadNLP.RelaxBound (they stay variables with both bounds, which
-    initialize relaxes by bound_relax_factor), "error" = refuse (MakeParameter, their elimination, is not built)."""
+    initialize relaxes by bound_relax_factor); anything else refuses them -- MakeParameter removes them before this
+    point (DeviceQP.eliminate_fixed), so none are left when that treatment is active."""
     ind_eq = np.flatnonzero(lcon == ucon)
     ind_ineq = np.flatnonzero(lcon != ucon)
     xl = np.concatenate([lvar, lcon[ind_ineq]])
     xu = np.concatenate([uvar, ucon[ind_ineq]])
     if np.any(xl == xu) and fixed_variable_treatment != "relax_bound":
-        raise NotImplementedError("fixed variables: pass fixed_variable_treatment='relax_bound' "
-                                  "(MakeParameter is not implemented)")
+        raise NotImplementedError("fixed variables: pass fixed_variable_treatment='relax_bound' or 'make_parameter'")
     return dict(ind_eq=ind_eq, ind_ineq=ind_ineq, ind_lb=np.flatnonzero(xl != -np.inf),
                 ind_ub=np.flatnonzero(xu != np.inf))
 
@@ -88,10 +88,22 @@ class MPCSolver:
     """``MPCSolver(nlp; opts...)`` (src/structure.jl:77-176) for a :class:`DeviceQP`."""
 
     def __init__(self, qp: DeviceQP, backend, **opts):
-        self.qp, self.be = qp, backend
+        self.be = backend
         self.opt = IPMOptions(**opts)
         host = lambda t: t.detach().cpu().numpy()
-        fvt = self.opt.fixed_variable_treatment or ("relax_bound" if self.opt.kkt_system in ("condensed", "augmented") else "error")
+        # src/utils.jl:81: RelaxBound for condensed KKT systems, MakeParameter otherwise
+        fvt = self.opt.fixed_variable_treatment or (
+            "relax_bound" if self.opt.kkt_system in ("condensed", "augmented") else "make_parameter")
+        if fvt not in ("relax_bound", "make_parameter", "error"):
+            raise ValueError(f"unknown fixed_variable_treatment {fvt!r}")
+        self.full_qp, self._fixed = qp, None
+        if fvt == "make_parameter":
+            self._fixed = qp.eliminate_fixed()
+            if self._fixed is not None:
+                qp = self._fixed[0]
+                if qp.nvar == 0:
+                    raise ValueError("every variable is fixed: nothing to optimise")
+        self.qp = qp
         ic = get_index_constraints(host(qp.lvar), host(qp.uvar), host(qp.lcon), host(qp.ucon), fvt)
         self.ind_ineq, self.ind_eq = ic["ind_ineq"], ic["ind_eq"]
         self.nx, self.ns = qp.nvar, len(self.ind_ineq)
@@ -499,12 +511,31 @@ class MPCSolver:
         # stats.constraints = A x of the unscaled model, from c = (A x - s - rhs) of the scaled one
         cons = h(st.c) + h(st.rhs)
         cons[self.ind_ineq] += h(st.x[nx:])
+        cons, y = cons / cs, h(st.y) * cs / self.obj_scale
+        zl, zu = h(st.zl[:nx]) / self.obj_scale, h(st.zu[:nx]) / self.obj_scale
+        if self._fixed is not None:  # MakeParameter: put the parameters back; their multipliers = reduced costs
+            _, free, fixed, xf, shift = self._fixed
+            free, fixed, fq = h(free), h(fixed), self.full_qp
+            n_full = fq.nvar
+            xs, zls, zus = np.zeros(n_full), np.zeros(n_full), np.zeros(n_full)
+            xs[free], xs[fixed], zls[free], zus[free] = x, h(xf), zl, zu
+            xd, yd = torch.as_tensor(xs, device=st.y.device), torch.as_tensor(y, device=st.y.device)
+            g = fq.q.clone()
+            if fq.H is not None:
+                g += fq.H * xd if fq.H.dim() == 1 else fq.H @ xd
+            if isinstance(fq.A, DeviceCSR):
+                g.index_add_(0, fq.A.col, fq.A.val * yd[fq.A.row])
+            elif fq.ncon:
+                g += fq.A.t() @ yd
+            r = h(g)[fixed]
+            zls[fixed], zus[fixed] = np.maximum(r, 0.0), np.maximum(-r, 0.0)
+            x, zl, zu, cons = xs, zls, zus, cons + h(shift)
         return dict(
             status=self.status, iter=self.k, objective=self.obj_val / self.obj_scale, solution=x,
-            constraints=cons / cs,
-            multipliers=h(st.y) * cs / self.obj_scale,
-            multipliers_L=h(st.zl[:nx]) / self.obj_scale,
-            multipliers_U=h(st.zu[:nx]) / self.obj_scale,
+            constraints=cons,
+            multipliers=y,
+            multipliers_L=zl,
+            multipliers_U=zu,
             trace=self.trace, n_factorizations=self.kkt.n_factorizations if self.kkt else 0,
             total_time=getattr(self, "total_time", 0.0),
             primal_feas=self.inf_pr, dual_feas=self.inf_du,  # stats.primal_feas / dual_feas of MadNLP.update!

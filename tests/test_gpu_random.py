@@ -89,8 +89,9 @@ def test_fixed_variables_relax_bound(hip):
         M.MPCSolver(to_device(qp, hip), hip, regularization=REG, fixed_variable_treatment="error")
     lp = Q.random_qp(6, 30, 12, lp=True)
     lp.lvar[2] = lp.uvar[2] = 0.1
-    with pytest.raises(NotImplementedError):  # NormalKKTSystem would use MakeParameter (not built)
-        M.MPCSolver(to_device(lp, hip), hip, kkt_system="normal", regularization=M.FixedRegularization(1e-8, 0.0))
+    with pytest.raises(NotImplementedError):
+        M.MPCSolver(to_device(lp, hip), hip, kkt_system="normal", regularization=M.FixedRegularization(1e-8, 0.0),
+                    fixed_variable_treatment="error")
     s = M.MPCSolver(to_device(lp, hip), hip, kkt_system="normal", regularization=M.FixedRegularization(1e-8, 0.0),
                     fixed_variable_treatment="relax_bound")
     r = s.solve()
@@ -112,3 +113,58 @@ def test_dummy_qp_with_fixed_variables(hip, eq):
         assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
         assert abs(r["objective"] - ref["objective"]) < 1e-5 and np.max(np.abs(r["solution"] - ref["solution"])) < 1e-5
         assert np.max(np.abs(r["solution"][:2])) < 1e-7
+
+
+@pytest.mark.parametrize("lp,ksys", [(True, "normal"), (False, "condensed"), (False, "augmented")])
+def test_fixed_variables_make_parameter(hip, lp, ksys):
+    """MadNLP.MakeParameter (src/utils.jl:81: the treatment of fixed variables for every KKT system that is not
+    condensed, i.e. the default with the normal equations): fixed variables leave the problem.  Checked against the
+    oracle on the hand-reduced model, and by the optimality conditions of the FULL model at the returned point;
+    dense and CSR Jacobian, dense and diagonal Hessian."""
+    import torch
+
+    qp = Q.random_qp(31, 50, 24, lp)
+    fixed = np.array([3, 8, 31, 49])
+    qp.lvar[fixed] = qp.uvar[fixed] = np.array([0.25, -0.4, 0.0, 0.1])
+    free = np.setdiff1d(np.arange(50), fixed)
+    xf = qp.lvar[fixed]
+    red = Q.DenseQP(H=qp.H[np.ix_(free, free)], q=qp.q[free] + qp.H[np.ix_(free, fixed)] @ xf, A=qp.A[:, free],
+                    lvar=qp.lvar[free], uvar=qp.uvar[free], lcon=qp.lcon - qp.A[:, fixed] @ xf,
+                    ucon=qp.ucon - qp.A[:, fixed] @ xf, x0=qp.x0[free],
+                    c0=qp.c0 + qp.q[fixed] @ xf + 0.5 * xf @ qp.H[np.ix_(fixed, fixed)] @ xf)
+    reg, oreg = (M.FixedRegularization(1e-8, 0.0), mpc.FixedRegularization(1e-8, 0.0)) if ksys != "condensed" else (REG, OREG)
+    ref = mpc.solve(red, kkt_system={"normal": "normal", "condensed": "condensed", "augmented": "K2"}[ksys],
+                    regularization=oreg)
+    assert ref["status"] == M.SOLVE_SUCCEEDED
+    kw = dict(kkt_system=ksys, regularization=reg, fixed_variable_treatment="make_parameter")
+    if ksys == "normal":
+        kw.pop("fixed_variable_treatment")  # the default there, as in the reference
+    for sparse in (False, True):
+        s = M.MPCSolver(to_device(qp, hip, sparse=sparse), hip, **kw)
+        assert s.nx == 46
+        r = s.solve()
+        s.close()
+        assert r["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
+        assert abs(r["objective"] - ref["objective"]) <= 1e-8 * max(1.0, abs(ref["objective"]))
+        x, y, zl, zu = r["solution"], r["multipliers"], r["multipliers_L"], r["multipliers_U"]
+        assert len(x) == 50 and np.array_equal(x[fixed], xf) and np.max(np.abs(x[free] - ref["solution"])) <= 1e-6
+        # optimality of the full model: stationarity with the parameters' reduced costs as their bound multipliers
+        assert np.max(np.abs(qp.H @ x + qp.q + qp.A.T @ y - zl + zu)) <= 1e-6
+        assert zl.min() >= 0 and zu.min() >= 0 and np.all(np.minimum(zl[fixed], zu[fixed]) == 0)
+        assert np.max(np.abs(r["constraints"] - qp.A @ x)) <= 1e-6
+    if not lp:  # diagonal Hessian as a vector
+        qd = Q.random_qp(31, 50, 24, False)
+        qd.H = np.diag(np.diag(qd.H))
+        qd.lvar[fixed] = qd.uvar[fixed] = xf
+        dq = to_device(qd, hip, sparse=True)
+        dq.H = torch.as_tensor(np.diag(qd.H).copy(), device=hip.device)
+        s = M.MPCSolver(dq, hip, kkt_system=ksys, regularization=reg, fixed_variable_treatment="make_parameter")
+        r = s.solve()
+        s.close()
+        x, y = r["solution"], r["multipliers"]
+        assert r["status"] == M.SOLVE_SUCCEEDED and np.array_equal(x[fixed], xf)
+        assert np.max(np.abs(qd.H @ x + qd.q + qd.A.T @ y - r["multipliers_L"] + r["multipliers_U"])) <= 1e-6
+        rb = M.MPCSolver(dq, hip, kkt_system=ksys, regularization=reg, fixed_variable_treatment="relax_bound")
+        r2 = rb.solve()
+        rb.close()
+        assert abs(r2["objective"] - r["objective"]) <= 1e-6 * max(1.0, abs(r["objective"]))  # both treatments agree
