@@ -89,13 +89,24 @@ static void run_panel(madqp_ctx* ctx, int64_t n, int64_t J0, int64_t W, int vari
            (long long)n, (long long)J0, (long long)W, variant, (long long)active, active / 512.0, ms,
            2.0 * active * 128 * 128 * g.K / (ms * 1e-3) * 1e-12, cyc.size() ? cyc[cyc.size() / 2] : 0.0,
            cyc.size() ? cyc[cyc.size() * 9 / 10] : 0.0);
+    std::vector<double> dur;  // per-workgroup wall time of its tile, ms (s_memrealtime ticks of 10 ns)
+    for (int64_t i = 0; i < nt; ++i) if (h[2 * i + 1]) dur.push_back((double)h[2 * i + 1] * 1e-5);
+    std::sort(dur.begin(), dur.end());
+    if (!dur.empty())
+        printf("    per-workgroup tile time ms: min %.3f p10 %.3f p50 %.3f p90 %.3f max %.3f (n=%zu)\n", dur.front(),
+               dur[dur.size() / 10], dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back(), dur.size());
     (void)hipFree(A); (void)hipFree(madqp_stamp_buffer); madqp_stamp_buffer = nullptr;
 }
 
 int main() {
     madqp_ctx* ctx;
     if (madqp_ctx_create(0, nullptr, &ctx)) return 1;
-    if (getenv("PROBE_PANEL")) {
+    if (getenv("PROBE_TAIL")) {  // single-round and few-round launches of the outer-panel update at C-main
+        run_panel(ctx, 50000, 43008, 1280, 0);
+        run_panel(ctx, 50000, 40960, 2048, 0);
+        run_panel(ctx, 50000, 32000, 1920, 0);
+        run_panel(ctx, 50000, 20864, 2048, 0);
+    } else if (getenv("PROBE_PANEL")) {
         run_panel(ctx, 49920, 20480, 2048, 0);
         run_panel(ctx, 50000, 20480, 2048, 0);
         run_panel(ctx, 49920, 30720, 1920, 0);
