@@ -113,6 +113,9 @@ __device__ __forceinline__ Prob prob_of(const BQ& q, int64_t b) {
 // lock-step iteration is the serial time of ONE problem's vector work.
 #define TPB 256
 #define WGNS wg256
+#ifdef MADQP_BATCH_STAMPS
+__device__ unsigned long long madqp_batch_stamps[32];  // [31] = last stamp; slot 0 = everything not listed
+#endif
 #include "batch_wg.inc"
 #undef TPB
 #undef WGNS
@@ -463,3 +466,14 @@ extern "C" int32_t madqp_batch_results(madqp_batch* b, int32_t* status_host, int
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MADQP_OK;
 }
+
+#ifdef MADQP_BATCH_STAMPS
+extern "C" int32_t madqp_batch_read_stamps(unsigned long long* out32, int32_t reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(madqp_batch_stamps), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(madqp_batch_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
