@@ -153,25 +153,23 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     P2_STAMP(0);
-    {  // lower triangle -> LDS: row r = tid & 127, columns (tid >> 7) + 2i; 16 loads in flight per thread
+    {  // lower triangle -> LDS: row r = tid & 127, columns (tid >> 7) + 2i; all 64 loads of a thread in flight at
+        // once (one HBM / L2 latency instead of four; the kernel runs alone on its CU, registers are free)
         const int r = tid & (NB - 1), c0 = tid >> 7;
+        double v[NB / 2];
 #pragma unroll
-        for (int i0 = 0; i0 < NB / 2; i0 += 16) {
-            double v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = c0 + 2 * (i0 + i);
-                double x = 0.0;
-                if (r < nb && c < nb) {
-                    if (r >= c) x = A[r + (int64_t)c * lda];
-                } else if (r == c) {
-                    x = 1.0;  // identity padding keeps the padded block positive definite
-                }
-                v[i] = x;
+        for (int i = 0; i < NB / 2; ++i) {
+            const int c = c0 + 2 * i;
+            double x = 0.0;
+            if (r < nb && c < nb) {
+                if (r >= c) x = A[r + (int64_t)c * lda];
+            } else if (r == c) {
+                x = 1.0;  // identity padding keeps the padded block positive definite
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) S[(c0 + 2 * (i0 + i)) * LDS_LD + r] = v[i];
+            v[i] = x;
         }
+#pragma unroll
+        for (int i = 0; i < NB / 2; ++i) S[(c0 + 2 * i) * LDS_LD + r] = v[i];
     }
     __syncthreads();
     P2_STAMP(1);
