@@ -49,6 +49,10 @@ def parse():
     p.add_argument("--no-distributed-extra", action="store_true",
                    help="N > 1: skip the additional strong-scaling measurement of the distributed KKT path")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-timers", action="store_true",
+                   help="do not time the MFMA kernel classes with event pairs (roofline.achieved is then 0): the "
+                        "pure throughput of small problems, whose factorisation is replayed as a hipGraph only when "
+                        "no events sit between its launches")
     p.add_argument("--cpu-sample-nx", type=int, default=8000)
     p.add_argument("--profile-all", action="store_true", help="time every kernel class (perturbs the "
                    "launch-bound ones); default times only the MFMA classes")
@@ -206,7 +210,7 @@ def measure(args, M, be, world, seed, distributed):
     for _ in range(args.warmup):
         step()
     mfma_classes = ("syrk", "potrf_gemm", "potrf_trsm", "potrf_diag")
-    be.prof_enable(M._lib.PROF_CLASSES if args.profile_all else mfma_classes)
+    be.prof_enable(() if args.no_kernel_timers else (M._lib.PROF_CLASSES if args.profile_all else mfma_classes))
     be.prof_reset()
     excluded = 0.0
     f0 = solver.kkt.n_factorizations
