@@ -135,7 +135,10 @@ struct Potf2Batch {  // problem blockIdx.x: pointer strides (doubles / ints); sk
     int64_t sA, sW, sInfo;
     const int32_t* skip;
 };
-__global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int nb,
+constexpr int P2_THREADS = 512;  // wave 0: the chain of 16 x 16 diagonal factorisations; waves 1..7: everything else
+// (1024 threads: loads and stores faster, the steps slower -- 45.2 vs 44.4 us: the early steps are bound by LDS
+// bank conflicts of the tile updates, not by the number of helper waves)
+__global__ __launch_bounds__(P2_THREADS) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int nb,
                                                         double* __restrict__ Wcm,
                                                         double* __restrict__ Wrm,
                                                         int32_t* __restrict__ info, int32_t col0,
@@ -153,13 +156,14 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     P2_STAMP(0);
-    {  // lower triangle -> LDS: row r = tid & 127, columns (tid >> 7) + 2i; all 64 loads of a thread in flight at
-        // once (one HBM / L2 latency instead of four; the kernel runs alone on its CU, registers are free)
+    {  // lower triangle -> LDS: row r = tid & 127, columns (tid >> 7) + CG*i; all loads of a thread in flight at
+        // once (one HBM / L2 latency; the kernel runs alone on its CU, registers are free)
+        constexpr int CG = P2_THREADS / NB;
         const int r = tid & (NB - 1), c0 = tid >> 7;
-        double v[NB / 2];
+        double v[NB / CG];
 #pragma unroll
-        for (int i = 0; i < NB / 2; ++i) {
-            const int c = c0 + 2 * i;
+        for (int i = 0; i < NB / CG; ++i) {
+            const int c = c0 + CG * i;
             double x = 0.0;
             if (r < nb && c < nb) {
                 if (r >= c) x = A[r + (int64_t)c * lda];
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
             v[i] = x;
         }
 #pragma unroll
-        for (int i = 0; i < NB / 2; ++i) S[(c0 + 2 * i) * LDS_LD + r] = v[i];
+        for (int i = 0; i < NB / CG; ++i) S[(c0 + CG * i) * LDS_LD + r] = v[i];
     }
     __syncthreads();
     P2_STAMP(1);
@@ -188,14 +192,53 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
 #pragma unroll
         for (int v = 0; v < 4; ++v) S[(SB * K + lo) * LDS_LD + SB * I + hi + 4 * v] = acc[v];
     };
+    // W = L^-1 is built inside the same eight steps by the helper waves (wave 0's 16-step chain is the critical
+    // path of a step): T_IJ' = sum_{K=J'}^{I-1} L_IK W_KJ' accumulates in the unused upper triangle (W(r, c) lives
+    // at S[r*LDS_LD + c], r > c) -- step J adds L_IJ W_JJ' for every I > J, J' <= J -- and row I is finished as
+    // W_IJ' = -W_II T_IJ' at the start of step I, once step I-1 has produced W_II.  The f64 accumulator layout
+    // (row = (lane>>4) + 4v) is the B-operand layout (k = 4s + (lane>>4)), so T feeds the second product from
+    // registers.  (As a separate phase after the factorisation this cost 8.4 us of the block's 58.)
+    auto t_update = [&](int J, int I, int Jp) {  // T_IJ' += L_IJ W_JJ'
+        double4_t T;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) T[v] = S[(SB * I + hi + 4 * v) * LDS_LD + SB * Jp + lo];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 4 * s + hi;
+            const double av = S[(SB * J + k) * LDS_LD + SB * I + lo];                   // L_IJ[lo][k]
+            const double bv = (Jp == J) ? Wd[(J * SB + k) * WD_LD + lo]                 // W_JJ[k][lo]
+                                        : S[(SB * J + k) * LDS_LD + SB * Jp + lo];      // W_JJ'[k][lo]
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) S[(SB * I + hi + 4 * v) * LDS_LD + SB * Jp + lo] = T[v];
+    };
+    auto w_finish = [&](int I, int Jp) {  // W_IJ' = -W_II T_IJ'
+        double4_t T, R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) T[v] = S[(SB * I + hi + 4 * v) * LDS_LD + SB * Jp + lo];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double av = Wd[(I * SB + lo) * WD_LD + 4 * s + hi];  // W_II[lo][4s+hi]
+            R = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[s], R, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) S[(SB * I + hi + 4 * v) * LDS_LD + SB * Jp + lo] = -R[v];
+    };
+    constexpr int NWV = P2_THREADS / 64, NH = NWV - 1;  // waves; helper waves 1..NH
     if (wave == 0) diag16_factor_invert(S, 0, Wd, info, col0, lane);
     __syncthreads();
     P2_STAMP(2);
     for (int J = 0; J < NSB; ++J) {
         const int b = J * SB;
         double* WdJ = Wd + J * SB * WD_LD;
-        // panel: L_IJ = A_IJ * W_JJ'
-        for (int I = J + 1 + wave; I < NSB; I += 4) {
+        // panel L_IJ = A_IJ * W_JJ' (I > J) and the rows W_JJ' (J' < J) of the inverse: 7 tile products
+        for (int o = wave; o < NSB - 1; o += NWV) {
+            if (o < J) {
+                w_finish(J, o);
+                continue;
+            }
+            const int I = o + 1;
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -209,8 +252,8 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
         __syncthreads();
         P2_STAMP(3 + 3 * J);
         // trailing update with look-ahead: wave 0 updates the next diagonal tile and factors it at once
-        // (the 16-step chain of diag16_factor_invert is the critical path) while waves 1..3 update the
-        // other tiles of this step
+        // (the 16-step chain of diag16_factor_invert is the critical path) while the helper waves update the
+        // other tiles of this step and the T tiles of the inverse
         if (J + 1 < NSB) {
             if (wave == 0) {
                 trailing_tile(J, J + 1, J + 1);
@@ -220,69 +263,41 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, 
                 for (int K = J + 1; K < NSB; ++K)
                     for (int I = K; I < NSB; ++I) {
                         if (K == J + 1 && I == J + 1) continue;
-                        if ((t++ % 3) + 1 == wave) trailing_tile(J, K, I);
+                        if ((t++ % NH) + 1 == wave) trailing_tile(J, K, I);
                     }
+                for (int I = J + 1; I < NSB; ++I)
+                    for (int Jp = 0; Jp <= J; ++Jp)
+                        if ((t++ % NH) + 1 == wave) t_update(J, I, Jp);
             }
         }
         __syncthreads();
         P2_STAMP(4 + 3 * J);
     }
-    // factor -> global (lower triangle only): row r = tid & 127, columns (tid >> 7) + 2i
+    // factor -> global (lower triangle only): row r = tid & 127, columns (tid >> 7) + CG*i
     {
+        constexpr int CG = P2_THREADS / NB;
         const int r = tid & (NB - 1), c0 = tid >> 7;
         if (r < nb) {
 #pragma unroll 8
-            for (int i = 0; i < NB / 2; ++i) {
-                const int c = c0 + 2 * i;
+            for (int i = 0; i < NB / CG; ++i) {
+                const int c = c0 + CG * i;
                 if (c <= r) A[r + (int64_t)c * lda] = S[c * LDS_LD + r];
             }
         }
     }
     P2_STAMP(26);
-    // W = L^-1: block columns {0}, {1,6}, {2,5,7}, {3,4} on waves 0..3 (balanced MFMA counts)
-    for (int q = 0; q < 3; ++q) {
-        int J;
-        if (q == 0)
-            J = wave;
-        else if (q == 1)
-            J = (wave == 0) ? -1 : 7 - wave;
-        else
-            J = (wave == 2) ? 7 : -1;
-        if (J < 0) continue;
-        for (int I = J + 1; I < NSB; ++I) {
-            double4_t T = {0.0, 0.0, 0.0, 0.0};
-            for (int K = J; K < I; ++K) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int k = 4 * s + hi;
-                    const double av = S[(SB * K + k) * LDS_LD + SB * I + lo];  // L_IK[lo][k]
-                    const double bv = (K == J) ? Wd[(J * SB + k) * WD_LD + lo]  // W_JJ[k][lo]
-                                               : S[(SB * K + k) * LDS_LD + SB * J + lo];  // W_KJ[k][lo]
-                    T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T, 0, 0, 0);
-                }
-            }
-            double4_t R = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double av = Wd[(I * SB + lo) * WD_LD + 4 * s + hi];  // W_II[lo][4s+hi]
-                R = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[s], R, 0, 0, 0);
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) S[(SB * I + hi + 4 * v) * LDS_LD + SB * J + lo] = -R[v];
-        }
-    }
-    __syncthreads();
     P2_STAMP(27);
     // only the lower triangles are written: the images are zero filled once when they are allocated
     {
+        constexpr int CG = P2_THREADS / NB;
         const int i = tid & (NB - 1), j0 = tid >> 7;
         auto W_at = [&](int r, int c) {
             return (r / SB == c / SB) ? Wd[r * WD_LD + c % SB] : S[r * LDS_LD + c];
         };
         if (i < nb) {
 #pragma unroll 8
-            for (int q = 0; q < NB / 2; ++q) {
-                const int j = j0 + 2 * q;
+            for (int q = 0; q < NB / CG; ++q) {
+                const int j = j0 + CG * q;
                 if (j <= i) Wcm[j * NB + i] = W_at(i, j);            // column-major: r = i (fast), c = j
                 if (j >= i && j < nb) Wrm[j * NB + i] = W_at(j, i);  // row-major:    c = i (fast), r = j
             }
@@ -648,7 +663,7 @@ static int32_t factor_block(madqp_chol* s, double* A, int64_t lda, int64_t jb, i
     double* Wrm = Wcm + NB * NB;
     {
         ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, ctx->stream, A + jb + jb * lda, lda,
+        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(P2_THREADS), 0, ctx->stream, A + jb + jb * lda, lda,
                            (int)w, Wcm, Wrm, s->d_info, (int32_t)jb, Potf2Batch{0, 0, 0, nullptr});
         LAUNCH_CHECK(ctx);
     }
@@ -774,7 +789,7 @@ int32_t bfactor_block(const CholBatch& c, int64_t jb, int64_t w) {
     double* Wcm = c.winv + (jb / NB) * WBLK;
     {
         ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3((unsigned)c.B), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(potf2_inv_kernel, dim3((unsigned)c.B), dim3(P2_THREADS), 0, ctx->stream,
                            c.A + jb + jb * c.lda, c.lda, (int)w, Wcm, Wcm + NB * NB, c.info, (int32_t)jb,
                            Potf2Batch{c.sA, c.sW, 1, c.skip});
         LAUNCH_CHECK(ctx);
