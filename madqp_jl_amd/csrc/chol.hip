@@ -28,7 +28,10 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 namespace {
 constexpr int NB = 128;    // diagonal block
 constexpr int NBO = 1024;  // outer panel
-constexpr int LDS_LD = NB + 1;
+#ifndef P2_LDS_LD
+#define P2_LDS_LD (NB + 1)
+#endif
+constexpr int LDS_LD = P2_LDS_LD;
 constexpr int64_t WBLK = 2 * NB * NB;  // doubles per block in chol->winv: [Wcm | Wrm]
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
