@@ -139,8 +139,7 @@ struct Potf2Batch {  // problem blockIdx.x: pointer strides (doubles / ints); sk
     const int32_t* skip;
 };
 constexpr int P2_THREADS = 512;  // wave 0: the chain of 16 x 16 diagonal factorisations; waves 1..7: everything else
-// (1024 threads: loads and stores faster, the steps slower -- 45.2 vs 44.4 us: the early steps are bound by LDS
-// bank conflicts of the tile updates, not by the number of helper waves)
+// (1024 threads: loads and stores faster, the steps slower -- 45.2 vs 44.4 us)
 __global__ __launch_bounds__(P2_THREADS) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int nb,
                                                         double* __restrict__ Wcm,
                                                         double* __restrict__ Wrm,
