@@ -4,7 +4,7 @@
 // dpotrf/dpotrs; reference call sites src/KKT/normalkkt.jl:99-101,196, src/linear_solver.jl:10-11).
 //
 // Factorisation, two levels of left-looking blocking so that >96 % of the flops run in wide GEMMs:
-//   for each outer panel J (768..2048 columns, chosen to fill the last round of workgroups)
+//   for each outer panel J (768..2560 columns, chosen to fill the last round of workgroups)
 //     C[J0:n, J]  -= L[J0:n, 0:J0] * L[J, 0:J0]'            gemm core, N = |J|,  K = J0   (MFMA)
 //     inside J, recursively: factor the first half, update the second half with it
 //       C[h:n, h:w] -= L[h:n, 0:h] * L[h:w, 0:h]'           gemm core, N = K = w/2        (MFMA)
@@ -603,7 +603,7 @@ extern "C" int32_t madqp_chol_destroy(madqp_chol* s) {
     return MADQP_OK;
 }
 
-// Width (multiple of 128, 768..2048) of the next outer panel: the wide update GEMM runs
+// Width (multiple of 128, 768..2560; up to 2048: +5 ms per iteration at C-main) of the next outer panel: the wide update GEMM runs
 // (rows/128) x (W/128) tiles of equal cost on `slots` resident workgroups, so W is chosen to
 // make the last round of tiles as full as possible (tail quantisation is the main loss of a
 // left-looking factorisation; 8 fixed tile columns leave the last round 5-50 % full).
@@ -612,7 +612,9 @@ static int64_t outer_panel_width(int64_t rows, bool has_update, int64_t slots) {
     if (!has_update || mt <= 6) return NBO;
     int64_t best = NBO / NB;
     double best_eff = -1.0;
-    for (int64_t wt = 6; wt <= 16 && wt <= mt; ++wt) {
+    static const int64_t wt_max = getenv("MADQP_CHOL_WMAX") ? atoll(getenv("MADQP_CHOL_WMAX")) : 20;
+    static const int64_t wt_min = getenv("MADQP_CHOL_WMIN") ? atoll(getenv("MADQP_CHOL_WMIN")) : 6;
+    for (int64_t wt = wt_min; wt <= wt_max && wt <= mt; ++wt) {
         const int64_t tiles = mt * wt - wt * (wt - 1) / 2;
         const int64_t rounds = (tiles + slots - 1) / slots;
         const double eff = (double)tiles / (double)(rounds * slots);
