@@ -187,3 +187,36 @@ def test_device_csr_container_on_cpu():
     assert np.array_equal(s.t_val.numpy(), (A * np.arange(1, 10)[:, None]).T[np.nonzero(A.T)])
     with pytest.raises(ValueError):
         DeviceCSR("cpu", 2, 2, [0, 0], [1, 1], [1.0, 2.0])
+
+
+@pytest.mark.parametrize("sparse,diag_h", [(False, False), (True, False), (True, True)])
+def test_make_parameter_elimination_on_cpu(sparse, diag_h):
+    """DeviceQP.eliminate_fixed (MadNLP.MakeParameter, src/utils.jl:81) is plain tensor algebra: checked here on
+    CPU tensors against the numpy reduction -- free part of H, q + H[:, fixed] x_fix, shifted row bounds, c0."""
+    qp = Q.random_qp(17, 30, 12, False)
+    if diag_h:
+        qp.H = np.diag(np.diag(qp.H))
+    fixed = np.array([0, 7, 29])
+    xf = np.array([0.3, -0.2, 0.05])
+    qp.lvar[fixed] = qp.uvar[fixed] = xf
+    free = np.setdiff1d(np.arange(30), fixed)
+    dq = M.DeviceQP.from_numpy(torch.device("cpu"), qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0,
+                               sparse=sparse)
+    if diag_h:
+        dq.H = torch.as_tensor(np.diag(qp.H).copy())
+    red, tfree, tfixed, txf, shift = dq.eliminate_fixed()
+    assert np.array_equal(tfree.numpy(), free) and np.array_equal(tfixed.numpy(), fixed) and np.array_equal(txf.numpy(), xf)
+    Hr = red.H.numpy() if not diag_h else np.diag(red.H.numpy())
+    assert np.allclose(Hr, qp.H[np.ix_(free, free)], rtol=0, atol=0)
+    assert np.allclose(red.q.numpy(), qp.q[free] + qp.H[np.ix_(free, fixed)] @ xf, rtol=1e-15, atol=1e-15)
+    Ar = red.A.to_dense().numpy() if sparse else red.A.numpy()
+    assert np.array_equal(Ar, qp.A[:, free])
+    s = qp.A[:, fixed] @ xf
+    assert np.allclose(shift.numpy(), s, atol=1e-15) and np.allclose(red.lcon.numpy(), qp.lcon - s, atol=1e-15)
+    assert abs(red.c0 - (qp.c0 + qp.q[fixed] @ xf + 0.5 * xf @ qp.H[np.ix_(fixed, fixed)] @ xf)) < 1e-14
+    assert red.nvar == 27 and red.ncon == 12 and np.array_equal(red.lvar.numpy(), qp.lvar[free])
+    # nothing fixed: nothing to do
+    qp2 = Q.random_qp(17, 30, 12, False)
+    dq2 = M.DeviceQP.from_numpy(torch.device("cpu"), qp2.H, qp2.q, qp2.A, qp2.lvar, qp2.uvar, qp2.lcon, qp2.ucon, qp2.x0)
+    if not np.any(qp2.lvar == qp2.uvar):
+        assert dq2.eliminate_fixed() is None
