@@ -22,8 +22,9 @@ def _np(t):
 
 
 class FakeKKT:
-    def __init__(self, nx, m, ind_ineq, H, A, normal=False):
-        self.normal = normal
+    def __init__(self, nx, m, ind_ineq, H, A, normal=False, augmented=False):
+        self.normal, self.augmented = normal, augmented
+        self.hdiag = None
         self.nx, self.m = nx, m
         self.ind_ineq = np.asarray(ind_ineq, dtype=np.int64)
         self.ns = len(self.ind_ineq)
@@ -281,6 +282,13 @@ class FakeBackend:
     def kkt_create_normal(self, nx, m, ind_ineq, At, ldat):
         return FakeKKT(nx, m, ind_ineq, None, At.t(), normal=True)
 
+    def kkt_create_augmented(self, nx, m, ind_ineq, H, ldh, A, lda):
+        return FakeKKT(nx, m, ind_ineq, H, A, augmented=True)
+
+    def kkt_set_hdiag(self, h, hdiag):
+        h.hdiag = _np(hdiag)
+        h.H = np.diag(h.hdiag)
+
     def kkt_destroy(self, h):
         pass
 
@@ -295,6 +303,20 @@ class FakeBackend:
         return th
 
     def kkt_build(self, h, st):
+        if h.augmented:  # [H + Sigma_x, A'; A, -D] (csrc/kkt.hip, mode AUGMENTED)
+            S, du = _np(st.pr_diag), _np(st.du_diag)
+            isq = h.slot >= 0
+            D = -du.copy()
+            D[isq] += 1.0 / S[h.nx + h.slot[isq]]
+            K = np.zeros((h.nx + h.m, h.nx + h.m))
+            if h.H is not None:
+                K[: h.nx, : h.nx] = h.H
+            K[np.arange(h.nx), np.arange(h.nx)] += S[: h.nx]
+            K[h.nx:, : h.nx] = h.A
+            K[: h.nx, h.nx:] = h.A.T
+            K[np.arange(h.nx, h.nx + h.m), np.arange(h.nx, h.nx + h.m)] = -D
+            h.K = K
+            return
         if h.normal:  # src/KKT/normalkkt.jl:166-180
             D = 1.0 / _np(st.pr_diag)
             K = (h.A * D[: h.nx]) @ h.A.T
@@ -313,6 +335,16 @@ class FakeBackend:
         if self.fail_factorizations > 0:
             self.fail_factorizations -= 1
             return 1
+        if h.augmented:  # quasi-definite: L diag(I, -I) L' exists iff both Cholesky factorisations below do
+            try:
+                nx = h.nx
+                L11 = sla.cholesky(h.K[:nx, :nx], lower=True, check_finite=False)
+                W = sla.solve_triangular(L11, h.K[:nx, nx:], lower=True, check_finite=False).T
+                L22 = sla.cholesky(W @ W.T - h.K[nx:, nx:], lower=True, check_finite=False) if h.m else np.zeros((0, 0))
+                h.chol = (L11, W, L22)
+                return 0
+            except sla.LinAlgError:
+                return 1
         try:
             h.chol = sla.cho_factor(h.K, lower=True, check_finite=False)
             return 0
@@ -324,6 +356,18 @@ class FakeBackend:
         wx, wy, _, _ = self._parts(st, w)
         nx, S = h.nx, _np(st.pr_diag)
         isq = h.slot >= 0
+        if h.augmented:
+            L11, W, L22 = h.chol
+            b2 = wy.copy()
+            b2[isq] += wx[nx + h.slot[isq]] / S[nx + h.slot[isq]]
+            z1 = sla.solve_triangular(L11, wx[:nx], lower=True, check_finite=False)
+            z2 = -sla.solve_triangular(L22, b2 - W @ z1, lower=True, check_finite=False) if h.m else b2
+            dy = sla.solve_triangular(L22, z2, lower=True, trans="T", check_finite=False) if h.m else b2
+            wx[:nx] = sla.solve_triangular(L11, z1 - W.T @ dy, lower=True, trans="T", check_finite=False)
+            wy[:] = dy
+            wx[nx + h.slot[isq]] = (wx[nx + h.slot[isq]] + dy[isq]) / S[nx + h.slot[isq]]
+            self.finish_aug_solve(st, w)
+            return
         if h.normal:  # src/KKT/normalkkt.jl:185-201
             r1 = wx / S
             u = h.A @ r1[:nx]

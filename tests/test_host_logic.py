@@ -220,3 +220,35 @@ def test_make_parameter_elimination_on_cpu(sparse, diag_h):
     dq2 = M.DeviceQP.from_numpy(torch.device("cpu"), qp2.H, qp2.q, qp2.A, qp2.lvar, qp2.uvar, qp2.lcon, qp2.ucon, qp2.x0)
     if not np.any(qp2.lvar == qp2.uvar):
         assert dq2.eliminate_fixed() is None
+
+
+@pytest.mark.parametrize("make", [Q.simple_lp, Q.hs21, lambda: Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)),
+                                  lambda: Q.random_qp(23, 40, 22, False), lambda: Q.random_qp(24, 35, 20, True)])
+def test_augmented_kkt_driver_matches_oracle(make):
+    """kkt_system="augmented" (HIPAugmentedKKTSystem, the K2 form) through the host control flow with the
+    reference's DEFAULT regularization (delta_d = 0) and equality rows: same trace as the oracle's K2 path."""
+    qp = make()
+    ref = mpc.solve(qp, kkt_system="K2")
+    _, r = run(qp, kkt_system="augmented", regularization=M.FixedRegularization(1e-8, 0.0))
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
+    for a, b in zip(r["trace"], ref["trace"]):
+        tol = 1e-9 if min(a["mu"], b["mu"]) >= 1e-4 else 1e-6
+        for k in ("alpha_p", "alpha_d", "inf_pr", "inf_du", "mu"):
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(b[k])), (a["k"], k)
+    assert np.max(np.abs(r["solution"] - ref["solution"])) < 1e-7
+    assert np.max(np.abs(r["multipliers"] - ref["multipliers"])) < 1e-6
+
+
+def test_augmented_kkt_options():
+    """Fixed variables default to RelaxBound for the augmented system (a condensed KKT type in the sense of
+    src/utils.jl:81); the inertia reported is the K2 one; the distributed factorisation refuses it."""
+    qp = Q.dummy_qp(20, 15, equality_cons=(0, 1), fixed_variables=(0, 1))
+    s, r = run(qp, kkt_system="augmented", regularization=M.FixedRegularization(1e-8, 0.0))
+    ref = mpc.solve(qp, kkt_system="K2", fixed_variable_treatment="relax_bound")
+    assert r["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
+    assert s.kkt.is_inertia_correct(*s.kkt.linear_solver.inertia())
+    assert s.kkt.linear_solver.inertia() == (20, 0, 15) and "L diag" in s.kkt.linear_solver.introduce()
+    with pytest.raises(ValueError):
+        run(qp, kkt_system="augmented", distributed=True)
+    with pytest.raises(ValueError):
+        run(qp, kkt_system="no-such-system")
