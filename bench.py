@@ -278,7 +278,9 @@ def main():
         what = ("ONE QP shared by all GPUs (panel-cyclic distributed assembly + Cholesky, madqp_jl_amd/dist.py)"
                 if shared else "one independent QP per GPU")
         out = {
-            "metric": "IPM iterations/sec (Mehrotra predictor-corrector, condensed KKT + Cholesky), dense QP fp64",
+            "metric": ("IPM iterations/sec (Mehrotra predictor-corrector, condensed KKT + Cholesky), dense QP fp64"
+                       if args.kkt_system == "condensed" else
+                       "IPM iterations/sec (Mehrotra predictor-corrector, augmented K2 KKT, L diag(I,-I) L'), dense QP fp64"),
             "value": (args.steps / tmax) if shared else job_value(world, args.steps, tmax),
             "unit": "iterations/s",
             "n_gpus": world,
@@ -295,8 +297,9 @@ def main():
                        "nx": nx, "m": m, "n_slack": m, "max_ncorr": args.max_ncorr,
                        "driver": "python" if shared else args.driver, "kkt": args.kkt,
                        "kkt_system": args.kkt_system,
-                       "options": "scripts/benchmarks_cpu.jl:35-44 with kkt_system=HIPCondensedKKTSystem, "
-                                  "linear_solver=HIPCholeskySolver"},
+                       "options": "scripts/benchmarks_cpu.jl:35-44 with kkt_system="
+                                  + ("HIPAugmentedKKTSystem" if args.kkt_system == "augmented" else "HIPCondensedKKTSystem")
+                                  + ", linear_solver=HIPCholeskySolver"},
             "kkt_factor_solve_ms": {
                 "assemble_syrk": prof["syrk"][0] / max(nfact, 1),
                 "factor_potrf": (prof["potrf_gemm"][0] + prof["potrf_trsm"][0] + prof["potrf_diag"][0]) / max(nfact, 1),
