@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--panel-width", type=int, default=None, help="block-column width of --kkt distributed")
     p.add_argument("--no-distributed-extra", action="store_true",
                    help="N > 1: skip the additional strong-scaling measurement of the distributed KKT path")
+    p.add_argument("--extra-timeout", type=float, default=240.0,
+                   help="N > 1: seconds after which the additional distributed-KKT measurement is given up")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timers", action="store_true",
                    help="do not time the MFMA kernel classes with event pairs (roofline.achieved is then 0): the "
@@ -252,14 +254,6 @@ def main():
     nx, m = args.nx, args.m
     shared = args.kkt == "distributed"
     res = measure(args, M, be, world, args.seed if shared else rank_seed(args.seed, rank), shared)
-    extra = None
-    if world > 1 and not shared and not args.no_distributed_extra:
-        # the same workload as ONE QP over all ranks (strong scaling of the distributed KKT path);
-        # reported beside the headline number, never instead of it
-        try:
-            extra = measure(args, M, be, world, args.seed, True)
-        except Exception as e:  # keep the headline line even if the extra leg fails
-            extra = {"error": f"{type(e).__name__}: {e}"[:300]}
     tmax, prof, nfact = res["tmax"], res["prof"], res["nfact"]
 
     if rank == 0:
@@ -319,21 +313,52 @@ def main():
         }
         if shared:
             out["distributed"] = {k: res[k] for k in ("panel_width", "panels", "bytes_broadcast_by_rank0")}
-        if extra is not None:
-            if "error" in extra:
-                out["distributed_kkt"] = extra
-            else:
-                ep = extra["prof"]
-                out["distributed_kkt"] = {
-                    "what": "the same workload as ONE QP over all GPUs (strong scaling; madqp_jl_amd/dist.py)",
-                    "value": args.steps / extra["tmax"], "unit": "iterations/s",
-                    "ms_per_step": extra["tmax"] / args.steps * 1e3, "scaling": "strong",
-                    "panel_width": extra["panel_width"], "panels": extra["panels"],
-                    "bytes_broadcast_by_rank0": extra["bytes_broadcast_by_rank0"],
-                    "rank0_ms": {k: ep[k][0] / max(extra["nfact"], 1) for k in ep if ep[k][1]},
-                }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, nx, m)
+    else:
+        out = None
+
+    if world > 1 and not shared and not args.no_distributed_extra:
+        # The same workload as ONE QP over all ranks (strong scaling of the distributed KKT path): reported beside
+        # the headline number, never instead of it -- the headline is complete at this point, and a watchdog prints
+        # it and ends the process should the extra leg not come back (a stuck collective raises nothing).
+        import threading
+
+        state = {"printed": False}
+        lock = threading.Lock()
+
+        def emit(extra_obj):
+            with lock:
+                if state["printed"]:
+                    return
+                state["printed"] = True
+                if rank == 0:
+                    out["distributed_kkt"] = extra_obj
+                    print(json.dumps(out), flush=True)
+
+        def bail():
+            emit({"error": f"no result after {args.extra_timeout} s"})
+            os._exit(0)
+
+        timer = threading.Timer(args.extra_timeout, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            extra = measure(args, M, be, world, args.seed, True)
+            ep = extra["prof"]
+            extra_obj = {
+                "what": "the same workload as ONE QP over all GPUs (strong scaling; madqp_jl_amd/dist.py)",
+                "value": args.steps / extra["tmax"], "unit": "iterations/s",
+                "ms_per_step": extra["tmax"] / args.steps * 1e3, "scaling": "strong",
+                "panel_width": extra["panel_width"], "panels": extra["panels"],
+                "bytes_broadcast_by_rank0": extra["bytes_broadcast_by_rank0"],
+                "rank0_ms": {k: ep[k][0] / max(extra["nfact"], 1) for k in ep if ep[k][1]},
+            }
+        except Exception as e:  # keep the headline line even if the extra leg fails
+            extra_obj = {"error": f"{type(e).__name__}: {e}"[:300]}
+        timer.cancel()
+        emit(extra_obj)
+    elif rank == 0:
         print(json.dumps(out), flush=True)
 
     be.close()
