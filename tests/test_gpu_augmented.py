@@ -204,3 +204,28 @@ def test_augmented_refuses_the_panel_pieces(hip):
     hip.chol_destroy(ch)
     with pytest.raises(ValueError):
         M.MPCSolver(to_device(Q.hs21(), hip), hip, kkt_system="augmented", distributed=True)
+
+
+K2_GOLDEN = {
+    "k2_simple_lp": (Q.simple_lp, 0), "k2_hs21": (Q.hs21, 0),
+    "k2_dummy_20_15_eq": (lambda: Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)), 0),
+    "k2_dummy_20_15_eq_gondzio": (lambda: Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)), 3),
+    "k2_random_40_22": (lambda: Q.random_qp(23, 40, 22, False), 0),
+}
+
+
+@DRIVERS
+@pytest.mark.parametrize("name", list(K2_GOLDEN))
+def test_augmented_golden_traces(hip, name, driver):
+    """The committed K2 fixtures (tests/golden/traces.json, generated by tests/golden/make_golden.py with the
+    reference's default options) through the augmented system on the device."""
+    import json
+    import os
+
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "traces.json")))[name]
+    make, ncorr = K2_GOLDEN[name]
+    r = solve_aug(make(), hip, driver=driver, max_ncorr=ncorr)
+    assert r["status"] == g["status"] == M.SOLVE_SUCCEEDED and r["iter"] == g["iter"]
+    compare_traces(r["trace"], g["trace"], name)
+    assert close(r["objective"], g["objective"], 1e-9)
+    assert np.max(np.abs(r["solution"] - np.array(g["solution"]))) <= 1e-7
