@@ -35,7 +35,11 @@ def parse():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--nx", type=int, default=50000)
     p.add_argument("--m", "--ncon", dest="m", type=int, default=20000)
-    p.add_argument("--max-ncorr", type=int, default=0)
+    p.add_argument("--max-ncorr", type=int, default=3,
+                   help="Gondzio corrections; 3 = scripts/benchmarks_cpu.jl:38 (the headline), 0 = the solver default "
+                        "src/utils.jl:94 (reported beside it as `max_ncorr_0`, SURVEY.md 8d)")
+    p.add_argument("--no-second-ncorr", action="store_true",
+                   help="skip the additional leg with the other max_ncorr setting (0 <-> 3)")
     p.add_argument("--seed", type=int, default=20250614 + 1)
     p.add_argument("--driver", choices=("native", "python"), default="native",
                    help="host driver of the loop body: csrc/mpc.hip (one C call per iteration) or solver.py")
@@ -182,50 +186,75 @@ def rank_seed(seed, rank):
     return seed + rank
 
 
-def measure(args, M, be, world, seed, distributed):
+class StepLoop:
+    """The timed unit and its bookkeeping.  A step = one predictor-corrector iteration (iteration_head +
+    iteration_body).  When the solve converges inside the loop the same instance is started again; the time of
+    that re-initialisation is excluded from the iteration time, but its start-point factorisation (src/solver.jl:21)
+    runs the same kernels under the same timers, so it COUNTS as a factorisation -- `factorizations()` reads the
+    solver's monotone counter (MPCSolver.n_factorizations_total), never a field of the KKT object that
+    initialize() replaces."""
+
+    def __init__(self, solver, sync=lambda: None):
+        self.solver, self.sync = solver, sync
+        self.reset()
+
+    def reset(self):
+        self.excluded, self.reinits, self.steps = 0.0, 0, 0
+        self._f0 = self.solver.n_factorizations_total
+
+    def factorizations(self):
+        return self.solver.n_factorizations_total - self._f0
+
+    def step(self):
+        s = self.solver
+        if s.iteration_head() is not None:  # converged: start the same instance again
+            self.sync()
+            t = time.perf_counter()
+            s.initialize()
+            s.iteration_head()
+            self.sync()
+            self.excluded += time.perf_counter() - t
+            self.reinits += 1
+        s.iteration_body()
+        self.steps += 1
+
+
+def measure(args, M, be, world, seed, distributed, max_ncorr=None, steps=None, warmup=None):
     """Warm-up + the timed region (barrier / sync on both sides, MAX over ranks) for one solver set-up:
     `distributed` False: this rank's own QP; True: all ranks share ONE QP."""
     import torch
 
     nx, m = args.nx, args.m
+    max_ncorr = args.max_ncorr if max_ncorr is None else max_ncorr
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     dq = M.DeviceQP.synthetic(be, seed, nx, m)
     # options of scripts/benchmarks_cpu.jl:35-44 (kkt_system -> condensed, linear_solver -> HIP Cholesky)
     solver = M.MPCSolver(dq, be, max_iter=300, step_rule=M.AdaptiveStep(0.995),
                          regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12,
-                         max_ncorr=args.max_ncorr, scaling=True, distributed=distributed,
+                         max_ncorr=max_ncorr, scaling=True, distributed=distributed,
                          panel_width=args.panel_width if distributed else None,
                          driver="python" if distributed else args.driver, kkt_system=args.kkt_system)
     solver.initialize()
-    excluded = 0.0  # time of re-initialisations inside the timed region (none unless it converges)
-
-    def step():
-        nonlocal excluded
-        if solver.iteration_head() is not None:  # converged: start the same instance again
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            solver.initialize()
-            solver.iteration_head()
-            torch.cuda.synchronize()
-            excluded += time.perf_counter() - t
-        solver.iteration_body()
-
-    for _ in range(args.warmup):
-        step()
+    loop = StepLoop(solver, torch.cuda.synchronize)
+    for _ in range(warmup):
+        loop.step()
     mfma_classes = ("syrk", "potrf_gemm", "potrf_trsm", "potrf_diag")
+    if nx >= 20000:  # millisecond-scale sweeps: an event pair around them perturbs nothing
+        mfma_classes += ("trsv",)
     be.prof_enable(() if args.no_kernel_timers else (M._lib.PROF_CLASSES if args.profile_all else mfma_classes))
     be.prof_reset()
-    excluded = 0.0
-    f0 = solver.kkt.n_factorizations
+    loop.reset()
     dist_barrier(world, cuda=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for _ in range(steps):
+        loop.step()
     dist_barrier(world, cuda=True)
-    elapsed = time.perf_counter() - t0 - excluded
+    elapsed = time.perf_counter() - t0 - loop.excluded
     prof = be.prof_get()
     be.prof_enable(())
     res = dict(tmax=max_over_ranks(elapsed, world, be.device), prof=prof,
-               nfact=solver.kkt.n_factorizations - f0, k=solver.k,
+               nfact=loop.factorizations(), reinits=loop.reinits, steps=steps, k=solver.k,
                last_trace={k: solver.trace[-1][k] for k in ("k", "inf_pr", "inf_du", "inf_compl", "mu")}
                if solver.trace else None)
     if distributed:
@@ -291,13 +320,20 @@ def main():
                        "nx": nx, "m": m, "n_slack": m, "max_ncorr": args.max_ncorr,
                        "driver": "python" if shared else args.driver, "kkt": args.kkt,
                        "kkt_system": args.kkt_system,
-                       "options": "scripts/benchmarks_cpu.jl:35-44 with kkt_system="
+                       "options": f"max_ncorr={args.max_ncorr}, FixedRegularization(1e-8,-1e-8), AdaptiveStep(0.995), "
+                                  "mu_min=1e-12, max_iter=300 (scripts/benchmarks_cpu.jl:35-44, whose max_ncorr is 3) "
+                                  "with kkt_system="
                                   + ("HIPAugmentedKKTSystem" if args.kkt_system == "augmented" else "HIPCondensedKKTSystem")
                                   + ", linear_solver=HIPCholeskySolver"},
+            # per factorisation (linear_solver_time / #factorizations, #factorizations = iterations +
+            # start points + x100 retries); solve = the triangular sweeps of all solves that follow one factorisation
             "kkt_factor_solve_ms": {
                 "assemble_syrk": prof["syrk"][0] / max(nfact, 1),
                 "factor_potrf": (prof["potrf_gemm"][0] + prof["potrf_trsm"][0] + prof["potrf_diag"][0]) / max(nfact, 1),
+                "solve_trsv": (prof["trsv"][0] / max(nfact, 1)) if prof["trsv"][1] else None,
+                "solves": prof["trsv"][1],
                 "factorizations": nfact,
+                "reinitializations_in_timed_region": res["reinits"],
                 "iteration_total": tmax / args.steps * 1e3,
             },
             "roofline": {
@@ -313,10 +349,21 @@ def main():
         }
         if shared:
             out["distributed"] = {k: res[k] for k in ("panel_width", "panels", "bytes_broadcast_by_rank0")}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, nx, m)
     else:
         out = None
+
+    if not args.no_second_ncorr and not shared:
+        # both max_ncorr settings are reported.  Same barrier / MAX-over-ranks protocol, fewer steps.
+        other = 0 if args.max_ncorr else 3
+        s2 = max(1, min(args.steps, 5))
+        r2 = measure(args, M, be, world, rank_seed(args.seed, rank), False, max_ncorr=other, steps=s2,
+                     warmup=min(args.warmup, 1))
+        if rank == 0:
+            out[f"max_ncorr_{other}"] = {"value": job_value(world, s2, r2["tmax"]), "unit": "iterations/s",
+                                         "ms_per_step": r2["tmax"] / s2 * 1e3, "steps": s2,
+                                         "factorizations": r2["nfact"], "solves": r2["prof"]["trsv"][1]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, nx, m)
 
     if world > 1 and not shared and not args.no_distributed_extra:
         # The same workload as ONE QP over all ranks (strong scaling of the distributed KKT path): reported beside
@@ -337,8 +384,10 @@ def main():
                     print(json.dumps(out), flush=True)
 
         def bail():
-            emit({"error": f"no result after {args.extra_timeout} s"})
-            os._exit(0)
+            # a collective that never returns is a fault, not a result: the completed headline line is printed, then
+            # EVERY rank ends with exit code 3 (nothing is retried in this process)
+            emit({"error": f"no result after {args.extra_timeout} s; exit code 3"})
+            os._exit(3)
 
         timer = threading.Timer(args.extra_timeout, bail)
         timer.daemon = True

@@ -55,6 +55,13 @@ int32_t madqp_ctx_create(int32_t device, void* stream, madqp_ctx** out);
 int32_t madqp_ctx_destroy(madqp_ctx* ctx);
 const char* madqp_last_error(madqp_ctx* ctx);
 int32_t madqp_ctx_sync(madqp_ctx* ctx);
+/* Device faults.  The triangular sweeps of madqp_chol_solve hand solved blocks from workgroup to workgroup; a
+ * consumer that waits longer than its spin limit sets a fault word on the device and finishes with NaNs.  The word
+ * travels with every scalar read-back (madqp_norm_inf3, madqp_get_alpha_max, ...): that call then returns
+ * MADQP_ERR_HIP ("triangular sweep hand-off timed out") and clears the word -- a hardware / scheduling fault is not
+ * reported as the numerical failure MadNLP.SolveException stands for (src/linear_solver.jl:41-43).
+ * madqp_debug_inject_fault sets the word (tests). */
+int32_t madqp_debug_inject_fault(madqp_ctx* ctx);
 /* device memory helpers for hosts without their own allocator (Julia glue, C++) */
 int32_t madqp_malloc(madqp_ctx* ctx, size_t bytes, void** out);
 int32_t madqp_free(madqp_ctx* ctx, void* ptr);

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "madqp_ctx_destroy": [vp],
     "madqp_last_error": [vp],
     "madqp_ctx_sync": [vp],
+    "madqp_debug_inject_fault": [vp],
     "madqp_malloc": [vp, C.c_size_t, C.POINTER(vp)],
     "madqp_free": [vp, vp],
     "madqp_memcpy_h2d": [vp, vp, vp, C.c_size_t],

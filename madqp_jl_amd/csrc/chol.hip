@@ -340,7 +340,7 @@ __device__ __forceinline__ void st_sc1_f64(double* p, double v) {
 // wave 0: wait until the 128 entries of block j of `x` have been published, copy them to LDS
 // (entries at or beyond n are zero).  Returns with the error flag set if the producer never shows up.
 __device__ __forceinline__ void sweep_poll_block(const double* __restrict__ x, int64_t j, int64_t n,
-                                                 double* __restrict__ dst, int32_t* __restrict__ err,
+                                                 double* __restrict__ dst, double* __restrict__ err,
                                                  int lane) {
     const int64_t i0 = j * NB + 2 * lane;
     unsigned long long u0 = 0, u1 = 0;
@@ -356,7 +356,7 @@ __device__ __forceinline__ void sweep_poll_block(const double* __restrict__ x, i
             wait1 = (u1 == SWEEP_SENTINEL);
         }
         if ((wait0 || wait1) && ++spins > SWEEP_SPIN_LIMIT) {
-            atomicExch(err, 1);
+            *err = 1.0;  // the context's fault word: read back with the next scalar result (madqp_read_results)
             u0 = u1 = 0x7FF8000000000000ull;
             break;
         }
@@ -414,7 +414,8 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
                                                               const double* __restrict__ winv,
                                                               const double* __restrict__ b,
                                                               double* __restrict__ y, int64_t n,
-                                                              int32_t* __restrict__ ctl, int vec) {
+                                                              int32_t* __restrict__ ctl, double* __restrict__ fault,
+                                                              int vec) {
     __shared__ double xs[2][NB];
     __shared__ double red[16][NB];
     __shared__ double vs[NB];
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     for (int j = 0; j < r; ++j) {
         const double* Tj = Lr + (int64_t)j * NB * lda;
         sweep_load_half(Tj + 64 * lda, lda, ok0, ok1, vec, B);
-        if (wave == 0) sweep_poll_block(y, j, n, xs[j & 1], &ctl[3], lane);
+        if (wave == 0) sweep_poll_block(y, j, n, xs[j & 1], fault, lane);
         __syncthreads();
         const double* xj = xs[j & 1];
 #pragma unroll
@@ -478,7 +479,8 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
                                                               const double* __restrict__ winv,
                                                               const double* __restrict__ y,
                                                               double* __restrict__ x, int64_t n,
-                                                              int32_t* __restrict__ ctl, int vec) {
+                                                              int32_t* __restrict__ ctl, double* __restrict__ fault,
+                                                              int vec) {
     __shared__ double xs[2][NB];
     __shared__ double red[16][NB];
     __shared__ double vs[NB];
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
         rows_ok(j, o0, o1);
         const double* Tj = Lc + (int64_t)j * NB;
         sweep_load_half(Tj + 64 * lda, lda, o0, o1, vec, B);
-        if (wave == 0) sweep_poll_block(x, j, n, xs[j & 1], &ctl[3], lane);
+        if (wave == 0) sweep_poll_block(x, j, n, xs[j & 1], fault, lane);
         __syncthreads();
         const double x0 = xs[j & 1][2 * lane], x1 = xs[j & 1][2 * lane + 1];
 #pragma unroll
@@ -572,7 +574,7 @@ extern "C" int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out
     hipError_t e = hipMalloc(&s->winv, nblk * WBLK * sizeof(double));
     if (e == hipSuccess) e = hipMemset(s->winv, 0, nblk * WBLK * sizeof(double));  // the kernel writes lower parts only
     if (e == hipSuccess) e = hipMalloc(&s->tmp, std::max<int64_t>(NB, n) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&s->d_info, 8 * sizeof(int32_t));  // [0] info, [1..3] sweep tickets / error
+    if (e == hipSuccess) e = hipMalloc(&s->d_info, 8 * sizeof(int32_t));  // [0] info, [1..2] sweep tickets
     if (e != hipSuccess) {
         madqp_chol_destroy(s);
         return madqp_fail(ctx, MADQP_ERR_ALLOC, "madqp_chol_create(%lld): %s", (long long)n,
@@ -991,7 +993,7 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
         HIP_TRY(ctx, hipMemsetAsync(s->d_info + 1, 0, 3 * sizeof(int32_t), ctx->stream));
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)s->tmp, 0x7FF8A5A5, 2 * (size_t)n, ctx->stream));
         hipLaunchKernelGGL(trsv_fwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, A, lda, s->winv, rhs,
-                           s->tmp, n, s->d_info, vec);
+                           s->tmp, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec);
         LAUNCH_CHECK(ctx);
         if (s->npos < n) {  // y <- diag(I, -I) y
             const int64_t len = n - s->npos;
@@ -1001,7 +1003,7 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
         }
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)rhs, 0x7FF8A5A5, 2 * (size_t)n, ctx->stream));
         hipLaunchKernelGGL(trsv_bwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, A, lda, s->winv,
-                           s->tmp, rhs, n, s->d_info, vec);
+                           s->tmp, rhs, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec);
         LAUNCH_CHECK(ctx);
     }
     return MADQP_OK;

@@ -11,6 +11,9 @@
 #include "../../include/madqp.h"
 
 #define MADQP_RESULT_SLOTS 64
+// last slot of the result block: device-side fault word (non-zero: a triangular sweep's hand-off timed out);
+// it rides along with every synchronising scalar read-back (madqp_read_results) and turns into MADQP_ERR_HIP
+#define MADQP_FAULT_SLOT (MADQP_RESULT_SLOTS - 1)
 
 struct ProfEvent {
     hipEvent_t a, b;

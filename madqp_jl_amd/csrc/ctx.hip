@@ -19,6 +19,7 @@ extern "C" int32_t madqp_ctx_create(int32_t device, void* stream, madqp_ctx** ou
             ctx->gemm_slots = 2 * (int64_t)cus;
     }
     if (e == hipSuccess) e = hipMalloc(&ctx->d_res, MADQP_RESULT_SLOTS * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(ctx->d_res, 0, MADQP_RESULT_SLOTS * sizeof(double));
     if (e == hipSuccess)
         e = hipHostMalloc((void**)&ctx->h_res, MADQP_RESULT_SLOTS * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess)
@@ -109,13 +110,31 @@ int32_t madqp_work_reserve(madqp_ctx* ctx, size_t bytes) {
     return MADQP_OK;
 }
 
-// Copies the first `count` slots of the device result block to the host (one sync).
+// Copies the first `count` slots of the device result block to the host (one sync).  The whole block (512 B)
+// travels, so the fault word in its last slot is seen by every scalar read-back: a sweep whose producer block never
+// published (chol.hip, sweep_poll_block) is reported as MADQP_ERR_HIP here instead of surfacing as quiet NaNs that
+// the loop would take for a numerical failure (src/linear_solver.jl:41-43).
 int32_t madqp_read_results(madqp_ctx* ctx, int count, double* out_host) {
-    ARG_TRY(ctx, count >= 0 && count <= MADQP_RESULT_SLOTS && out_host);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, count * sizeof(double), hipMemcpyDeviceToHost,
+    ARG_TRY(ctx, count >= 0 && count < MADQP_FAULT_SLOT && out_host);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_res, MADQP_RESULT_SLOTS * sizeof(double), hipMemcpyDeviceToHost,
                                 ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out_host, ctx->h_res, count * sizeof(double));
+    if (ctx->h_res[MADQP_FAULT_SLOT] != 0.0) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res + MADQP_FAULT_SLOT, 0, sizeof(double), ctx->stream));
+        return madqp_fail(ctx, MADQP_ERR_HIP,
+                          "triangular sweep hand-off timed out: a producer block never published its solution "
+                          "(device fault word set; results of the last solve are invalid)");
+    }
+    return MADQP_OK;
+}
+
+// Test hook: sets the device fault word as a timed-out sweep would.
+extern "C" int32_t madqp_debug_inject_fault(madqp_ctx* ctx) {
+    ARG_TRY(ctx, ctx != nullptr);
+    const double one = 1.0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_res + MADQP_FAULT_SLOT, &one, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MADQP_OK;
 }
 

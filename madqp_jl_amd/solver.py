@@ -145,6 +145,15 @@ class MPCSolver:
             raise ValueError("the native driver factorizes on one GPU; use driver='python' with distributed=True")
         self._native = None  # madqp_mpc handle (driver="native")
         self._info = CMpcInfo()
+        self._fact_closed = 0  # factorizations of KKT objects that initialize() has already released
+
+    @property
+    def n_factorizations_total(self) -> int:
+        """Factorizations since this solver was constructed: monotone over re-initialisations (``initialize``
+        releases and recreates the KKT object, whose own counter restarts at 0).  counters of
+        scripts/benchmarks_cpu.jl:52-55 are per solve; a benchmark that re-initialises inside its timed region
+        reads this one."""
+        return self._fact_closed + (self.kkt.n_factorizations if self.kkt is not None else 0)
 
     # ---- driver="native": the loop body runs in csrc/mpc.hip, one foreign call per iteration ----
     def _native_open(self):
@@ -351,7 +360,9 @@ class MPCSolver:
                 self.H = None if qp.H is None else (self.obj_scale * qp.H).contiguous()
                 self.q = self.obj_scale * qp.q
         if self.kkt is not None:
+            self._fact_closed += self.kkt.n_factorizations
             self.kkt.close()
+            self.kkt = None
         extra = {}
         if opt.distributed:  # one KKT system over the ranks of the default process group
             from . import dist as D

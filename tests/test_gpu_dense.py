@@ -221,3 +221,17 @@ def test_pointers_aligned_to_8_bytes_only(hip):
         assert np.linalg.norm(K @ xs - b) / (np.linalg.norm(K) * np.linalg.norm(xs)) < 1e-14
     finally:
         hip.chol_destroy(h)
+
+
+def test_sweep_timeout_is_reported_as_a_device_fault(hip):
+    """A triangular sweep whose producer block never publishes sets the context's fault word (chol.hip,
+    sweep_poll_block); the next scalar read-back must return MADQP_ERR_HIP with its own message instead of letting
+    the NaNs pass for MadNLP.SolveException (src/linear_solver.jl:41-43).  The word is injected here."""
+    import madqp_jl_amd as M
+
+    v = torch.full((9,), -3.0, dtype=torch.float64, device=hip.device)
+    assert hip.norm_inf(v) == 3.0
+    hip._ck(hip.lib.madqp_debug_inject_fault(hip.ctx))
+    with pytest.raises(M.MadQPError, match="hand-off timed out"):
+        hip.norm_inf(v)
+    assert hip.norm_inf(v) == 3.0  # reported once, then cleared
