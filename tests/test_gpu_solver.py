@@ -161,7 +161,23 @@ def test_kkt_system_conformance(hip, with_eq):
     be.fill(0.0, st.w1)
     s.kkt.mul(st.w1, st.d, 1.0, 0.0)
     res = np.max(np.abs(st.w1.cpu().numpy() - b)) / max(1.0, np.max(np.abs(b)))
-    assert res < (1e-5 if with_eq else 1e-10), res
+    # The same check through the oracle's condensed system (LAPACK dpotrf / dpotrs) on the same data is the floor of
+    # this FORMULATION: an equality row enters as Theta = -1/delta_d = 1e8, cond(K) = 3.6e7, and the decondensation
+    # dy = Theta (A dx - t) multiplies the error of dx by 1e8 -- LAPACK reaches 2.3e-7 here, 3e-12 without equality
+    # rows.  The device path must stay within a small factor of that floor (it measured 3.5e-7); the formulation that
+    # takes equality rows exactly reaches 1e-10 on this check (test_gpu_augmented.py::test_augmented_kkt_conformance).
+    o = mpc.MPCSolver(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8))
+    o.initialize()
+    o.del_w, o.del_c = 1e-8, -1e-8
+    o.set_aug_diagonal_reg()
+    o.kkt.build_and_factorize()
+    o.d.values[:] = b
+    o.kkt.solve(o.d)
+    ow = mpc.KKTVec(o.n, o.m, o.nlb, o.nub, o.ind_lb, o.ind_ub)
+    o.kkt.mul(ow, o.d, 1.0, 0.0)
+    res_oracle = np.max(np.abs(ow.values - b)) / max(1.0, np.max(np.abs(b)))
+    assert res_oracle < (1e-6 if with_eq else 1e-10), res_oracle
+    assert res < max(4.0 * res_oracle, 1e-11), (res, res_oracle)
     # jtprod vs explicit Jacobian [A, -I_ineq]
     y = rng.standard_normal(st.m)
     yd = torch.as_tensor(y, device=be.device)
