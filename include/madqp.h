@@ -280,6 +280,22 @@ int32_t madqp_kkt_create_sparse(madqp_ctx* ctx, int32_t mode, int64_t nx, int64_
  * extension of the LP-only NormalKKTSystem (src/KKT/normalkkt.jl:45-48) that CONT-type QPs need. */
 int32_t madqp_kkt_set_hdiag(madqp_kkt* kkt, const double* hdiag);
 
+/* ----------------------------------------- callback buffers -> dense operands */
+/* MadNLP.SparseCallback hands the Jacobian / Hessian values as nnz-long buffers in the order of the model's COO
+ * pattern (get_jacobian / get_hessian, src/KKT/normalkkt.jl:129-130, filled at src/solver.jl:167,170).
+ * compress_jacobian! (src/KKT/normalkkt.jl:149-158, through A_csr_map) and compress_hessian! (the scatter-add
+ * transfer! of scripts/cuda_wrapper.jl:9-34) move them into the matrix storage; for the DENSE operands of this
+ * library that is a madqp_coo_map: built once from the pattern (I_host, J_host: 1-based, as MadNLP keeps them),
+ * applied after every callback evaluation.  apply: dst(i, j) at dst[i*ld + j] (row i contiguous -- A as
+ * madqp_kkt_create wants it) = sum of the values whose pattern entry is (i+1, j+1), added in COO order by ONE lane
+ * (no atomics, reproducible); every other entry of the nrows x ncols target is set to 0.  symmetric != 0: the pattern
+ * is one triangle of a symmetric matrix (MadNLP's Hessians are lower triangular) and both halves are written. */
+typedef struct madqp_coo_map madqp_coo_map;
+int32_t madqp_coo_map_create(madqp_ctx* ctx, int64_t nnz, const int32_t* I_host, const int32_t* J_host,
+                             int64_t nrows, int64_t ncols, int32_t symmetric, madqp_coo_map** out);
+int32_t madqp_coo_map_apply(madqp_coo_map* map, const double* vals, double* dst, int64_t ld);
+int32_t madqp_coo_map_destroy(madqp_coo_map* map);
+
 /* ----------------------------------------- multi-GPU factorisation pieces */
 /* One dense KKT over several GPUs, one process per GPU: block columns ("panels", starts and widths
  * multiples of 128, the last one may be short) are dealt round-robin to the ranks.  A rank assembles

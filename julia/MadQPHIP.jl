@@ -1,15 +1,16 @@
 # MadQPHIP.jl -- Julia glue that drops libmadqp_hip.so into MadIPM's solver loop.
 #
-# STATUS: written against the MadNLP 0.8.x plugin contract as used by MadIPM
-# (/root/reference/src/KKT/normalkkt.jl, src/linear_solver.jl, src/kernels.jl); it has NOT been
-# executed in the authoring environment (no Julia toolchain there, SURVEY.md section 0).  Every
-# ccall below binds one prototype of include/madqp.h; the same ABI is exercised end to end by the
-# Python host mirror (madqp_jl_amd/) and its GPU tests.
+# STATUS: UNVERIFIED UNDER JULIA.  No Julia toolchain exists in the authoring or GPU image (SURVEY.md section 0), so
+# this file has never been executed.  What IS executed: every ccall below binds one prototype of include/madqp.h,
+# and tests/test_gpu_julia_replay.py replays -- through ctypes, entry point by entry point, in the order MadIPM
+# issues them (src/solver.jl:6-125,127-182,254-345) -- exactly the call sequence of the methods of this file, each
+# replay function named after the Julia method it stands for.  A change here needs the same change there.
 #
-# What it provides
-#   HIPCondensedKKTSystem <: MadNLP.AbstractKKTSystem   (modelled on NormalKKTSystem)
-#   HIPCholeskySolver     <: MadNLP.AbstractLinearSolver
-#   methods of MadIPM's per-variable kernels specialised on HIPCondensedKKTSystem so that `mpc!`
+# What it provides (SURVEY.md 8b)
+#   HIPCondensedKKTSystem / HIPAugmentedKKTSystem / HIPNormalKKTSystem  <: MadNLP.AbstractKKTSystem
+#       (modelled on NormalKKTSystem, src/KKT/normalkkt.jl; same generic fields, same methods)
+#   HIPCholeskySolver <: MadNLP.AbstractLinearSolver   (ctor `Solver(aug_com; opt)`, factorize!, solve!(s, rhs))
+#   methods of MadIPM's per-variable kernels (src/kernels.jl) specialised on these KKT types, so that `mpc!`
 #   (src/solver.jl:254-345) runs unchanged with every vector on the device.
 #
 # Usage
@@ -23,6 +24,7 @@ module MadQPHIP
 import MadNLP
 import MadIPM
 using LinearAlgebra
+import LinearAlgebra: mul!
 
 const libmadqp = get(ENV, "MADQP_HIP_LIB", "libmadqp_hip.so")
 
@@ -43,7 +45,7 @@ last_error(ctx::Context) = unsafe_string(ccall((:madqp_last_error, libmadqp), Cs
 
 function check(ctx::Context, rc::Int32)
     rc == 0 && return
-    rc < 0 && error("libmadqp_hip: $(last_error(ctx)) ($rc)")
+    rc < 0 && error("libmadqp_hip: $(last_error(ctx)) ($rc)")     # usage / device fault
     throw(MadNLP.SolveException())        # rc > 0: numerical condition (src/linear_solver.jl:41-43)
 end
 
@@ -60,159 +62,266 @@ struct CState
 end
 
 dptr(v) = Base.unsafe_convert(Ptr{eltype(v)}, v)     # ROCArray -> device pointer
+const NULLF = Ptr{Float64}(C_NULL)
 
 # --------------------------------------------------------------------------- linear solver
-mutable struct HIPCholeskySolver{T} <: MadNLP.AbstractLinearSolver{T}
-    kkt_handle::Ptr{Cvoid}                # the library object that owns K and its factor
+# `aug_com`: the matrix object the linear-solver constructor receives once and re-reads at every factorize!
+# (src/KKT/normalkkt.jl:97-101).  Here the matrix (K, later its factor) lives in the library's KKT object; this is the
+# handle to it.
+mutable struct HIPDenseKKTMatrix{T}
+    handle::Ptr{Cvoid}        # madqp_kkt*
     ctx::Context
+    order::Int
+    maps::Vector{Ptr{Cvoid}}  # madqp_coo_map handles that live as long as the KKT object
+    function HIPDenseKKTMatrix{T}(handle, ctx, order, maps) where {T}
+        A = new{T}(handle, ctx, order, maps)
+        finalizer(A) do a       # ownership: the library frees what it allocated (SURVEY.md 8b)
+            ccall((:madqp_kkt_destroy, libmadqp), Int32, (Ptr{Cvoid},), a.handle)
+            foreach(mp -> ccall((:madqp_coo_map_destroy, libmadqp), Int32, (Ptr{Cvoid},), mp), a.maps)
+        end
+        return A
+    end
+end
+Base.size(A::HIPDenseKKTMatrix) = (A.order, A.order)
+Base.eltype(::HIPDenseKKTMatrix{T}) where {T} = T
+
+MadNLP.@kwdef mutable struct HIPCholeskyOptions <: MadNLP.AbstractOptions end
+
+mutable struct HIPCholeskySolver{T} <: MadNLP.AbstractLinearSolver{T}
+    aug_com::HIPDenseKKTMatrix{T}
+    chol::Ptr{Cvoid}          # madqp_chol* of the KKT object (borrowed)
     info::Int32
-    opt::MadNLP.AbstractOptions
+    opt::HIPCholeskyOptions
     logger::MadNLP.MadNLPLogger
 end
 
-MadNLP.@kwdef mutable struct HIPCholeskyOptions <: MadNLP.AbstractOptions end
+# src/KKT/normalkkt.jl:99-101: `linear_solver(aug_com; opt = opt_linear_solver)`
+function HIPCholeskySolver(aug_com::HIPDenseKKTMatrix{T}; opt = HIPCholeskyOptions(),
+                           logger = MadNLP.MadNLPLogger()) where {T}
+    chol = Ref{Ptr{Cvoid}}(C_NULL)
+    order = Ref{Int64}(0)
+    check(aug_com.ctx, ccall((:madqp_kkt_chol, libmadqp), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Int64}),
+                             aug_com.handle, chol, order))
+    return HIPCholeskySolver{T}(aug_com, chol[], Int32(0), opt, logger)
+end
+
 MadNLP.default_options(::Type{HIPCholeskySolver}) = HIPCholeskyOptions()
 MadNLP.introduce(::HIPCholeskySolver) = "madqp-hip blocked left-looking fp64 Cholesky (MFMA, gfx950)"
 MadNLP.is_supported(::Type{HIPCholeskySolver}, ::Type{Float64}) = true
 MadNLP.is_inertia(::HIPCholeskySolver) = true
-MadNLP.inertia(s::HIPCholeskySolver) = s.info == 0 ? (typemax(Int), 0, 0) : (Int(s.info) - 1, 0, 1)
+MadNLP.inertia(s::HIPCholeskySolver) = s.info == 0 ? (s.aug_com.order, 0, 0) : (Int(s.info) - 1, 0, 1)
 MadNLP.improve!(::HIPCholeskySolver) = false
 MadIPM.is_factorized(s::HIPCholeskySolver) = s.info == 0        # src/utils.jl:54-62
 
-function MadNLP.factorize!(s::HIPCholeskySolver)
+function MadNLP.factorize!(s::HIPCholeskySolver)                 # via factorize_wrapper!, src/linear_solver.jl:10
     info = Ref{Int32}(0)
-    check(s.ctx, ccall((:madqp_kkt_factorize, libmadqp), Int32, (Ptr{Cvoid}, Ref{Int32}), s.kkt_handle, info))
+    check(s.aug_com.ctx, ccall((:madqp_kkt_factorize, libmadqp), Int32, (Ptr{Cvoid}, Ref{Int32}), s.aug_com.handle, info))
     s.info = info[]              # > 0: not positive definite -> x100 regularization retry (src/linear_solver.jl:11-15)
     return s
 end
 
+# src/KKT/normalkkt.jl:196: `MadNLP.solve!(kkt.linear_solver, r2)`, in place
+function MadNLP.solve!(s::HIPCholeskySolver, rhs::AbstractVector)
+    check(s.aug_com.ctx, ccall((:madqp_chol_solve, libmadqp), Int32, (Ptr{Cvoid}, Ptr{Float64}), s.chol, dptr(rhs)))
+    return rhs
+end
+
 # --------------------------------------------------------------------------- KKT system
-struct HIPCondensedKKTSystem{T, VT, MT, QN, VI} <: MadNLP.AbstractKKTSystem{T, VT, MT, QN}
+# F = :condensed  K = H + Sigma_x + A' Theta A            (madqp_kkt_create)
+#     :augmented  [H + Sigma_x, A'; A, -D], L diag(I,-I) L' (madqp_kkt_create_augmented; MadNLP's default K2 form)
+#     :normal     A Sigma^-1 A', LP only                  (madqp_kkt_create_normal; the reference's NormalKKTSystem)
+struct HIPKKTSystem{T, VT, MT, QN, VI, LS, F} <: MadNLP.AbstractKKTSystem{T, VT, MT, QN}
+    aug_com::HIPDenseKKTMatrix{T}
     handle::Ptr{Cvoid}
     ctx::Context
-    H::MT                 # nx x nx dense symmetric (device)
-    At::MT                # nx x m column-major == A with row k contiguous (device)
-    jac::VT               # callback buffers (dense row-major Jacobian / Hessian values)
-    hess::VT
+    H::MT                 # nx x nx dense symmetric (device); 0 x 0 for an LP
+    At::MT                # dense Jacobian operand (device): nx x m Julia matrix (= A with row k contiguous) for the
+                          # condensed / augmented forms, m x nx Julia matrix (= A' with variable k contiguous) for :normal
+    lda::Int              # its leading dimension as the library sees it (nx, or m for :normal)
+    jac::VT               # nnzj callback buffer (get_jacobian), COO order of the model's pattern
+    hess::VT              # nnzh callback buffer (get_hessian)
+    jac_map::Ptr{Cvoid}   # madqp_coo_map: jac -> At
+    hess_map::Ptr{Cvoid}  # madqp_coo_map: hess -> H (symmetric)
     # fields MadIPM reads generically (src/kernels.jl:135-144, src/solver.jl:16-18)
     reg::VT; pr_diag::VT; du_diag::VT
     l_diag::VT; u_diag::VT; l_lower::VT; u_lower::VT
-    linear_solver::HIPCholeskySolver{T}
+    linear_solver::LS
     ind_ineq::VI; ind_lb::VI; ind_ub::VI      # 1-based, as MadNLP keeps them
     ind_lb0::VI; ind_ub0::VI                  # 0-based device copies handed to the library
+    cstate::Base.RefValue{CState}             # view with the KKT's own fields only (build_kkt!, solve!, mul!)
     n::Int; m::Int; nx::Int
 end
+const HIPCondensedKKTSystem = HIPKKTSystem{T, VT, MT, QN, VI, LS, :condensed} where {T, VT, MT, QN, VI, LS}
+const HIPAugmentedKKTSystem = HIPKKTSystem{T, VT, MT, QN, VI, LS, :augmented} where {T, VT, MT, QN, VI, LS}
+const HIPNormalKKTSystem = HIPKKTSystem{T, VT, MT, QN, VI, LS, :normal} where {T, VT, MT, QN, VI, LS}
+form(::HIPKKTSystem{T, VT, MT, QN, VI, LS, F}) where {T, VT, MT, QN, VI, LS, F} = F
 
-function MadNLP.create_kkt_system(
-    ::Type{HIPCondensedKKTSystem}, cb::MadNLP.AbstractCallback{T, VT}, ind_cons, linear_solver::Type;
-    opt_linear_solver = MadNLP.default_options(linear_solver),
-    hessian_approximation = MadNLP.ExactHessian, qn_options = MadNLP.QuasiNewtonOptions(),
-) where {T, VT}
+function coo_map(ctx::Context, I::Vector{Int32}, J::Vector{Int32}, nrows, ncols, symmetric)
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ctx, ccall((:madqp_coo_map_create, libmadqp), Int32,
+                     (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Int64, Int64, Int32, Ref{Ptr{Cvoid}}),
+                     ctx.ptr, length(I), I, J, nrows, ncols, symmetric, ref))
+    return ref[]
+end
+
+function _create(F::Symbol, cb::MadNLP.SparseCallback{T, VT}, ind_cons, linear_solver::Type, opt_linear_solver) where {T, VT}
     nx, m = cb.nvar, cb.ncon
     ind_ineq = ind_cons.ind_ineq
     ns = length(ind_ineq)
     n = nx + ns
     nlb, nub = length(ind_cons.ind_lb), length(ind_cons.ind_ub)
+    if F == :normal && cb.nnzh > 0                                    # src/KKT/normalkkt.jl:45-48
+        error("The KKT system NormalKKTSystem supports only linear programs.")
+    end
     ctx = Context()
-    H = fill!(similar(VT, nx * nx), zero(T)); H = reshape(H, nx, nx)
-    At = fill!(similar(VT, nx * m), zero(T)); At = reshape(At, nx, m)
+    # sparsity patterns of the callbacks (src/KKT/normalkkt.jl:51-53)
+    jI = MadNLP.create_array(cb, Int32, cb.nnzj); jJ = MadNLP.create_array(cb, Int32, cb.nnzj)
+    MadNLP._jac_sparsity_wrapper!(cb, jI, jJ)
+    hI = MadNLP.create_array(cb, Int32, cb.nnzh); hJ = MadNLP.create_array(cb, Int32, cb.nnzh)
+    cb.nnzh > 0 && MadNLP._hess_sparsity_wrapper!(cb, hI, hJ)
+    jIh, jJh = Vector{Int32}(Array(jI)), Vector{Int32}(Array(jJ))
+    # target of the Jacobian values: entry (i, k) of A at [i*nx + k] (rows of A contiguous), or, for the normal
+    # equations, at [k*m + i] (rows of A' contiguous: the pattern is handed over transposed)
+    jac_map = F == :normal ? coo_map(ctx, jJh, jIh, nx, m, 0) : coo_map(ctx, jIh, jJh, m, nx, 0)
+    hess_map = cb.nnzh > 0 ? coo_map(ctx, Vector{Int32}(Array(hI)), Vector{Int32}(Array(hJ)), nx, nx, 1) : C_NULL
+    nh = cb.nnzh > 0 ? nx : 0
+    H = reshape(fill!(VT(undef, nh * nh), zero(T)), nh, nh)
+    At = F == :normal ? reshape(fill!(VT(undef, nx * m), zero(T)), m, nx) :
+                        reshape(fill!(VT(undef, nx * m), zero(T)), nx, m)
+    lda = F == :normal ? max(m, 1) : max(nx, 1)
     mk(k) = VT(undef, k)
     ref = Ref{Ptr{Cvoid}}(C_NULL)
     ineq0 = Int64.(Array(ind_ineq)) .- 1
-    rc = ccall((:madqp_kkt_create, libmadqp), Int32,
-               (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ref{Ptr{Cvoid}}),
-               ctx.ptr, nx, m, ns, ineq0, dptr(H), nx, dptr(At), nx, ref)
+    Hp = nh > 0 ? dptr(H) : NULLF
+    if F == :condensed
+        rc = ccall((:madqp_kkt_create, libmadqp), Int32,
+                   (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ref{Ptr{Cvoid}}),
+                   ctx.ptr, nx, m, ns, ineq0, Hp, max(nx, 1), dptr(At), lda, ref)
+    elseif F == :augmented
+        rc = ccall((:madqp_kkt_create_augmented, libmadqp), Int32,
+                   (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ref{Ptr{Cvoid}}),
+                   ctx.ptr, nx, m, ns, ineq0, Hp, max(nx, 1), dptr(At), lda, ref)
+    else   # A' with variable k contiguous = a Julia m x nx matrix as it stands
+        rc = ccall((:madqp_kkt_create_normal, libmadqp), Int32,
+                   (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Ptr{Cvoid}}),
+                   ctx.ptr, nx, m, ns, ineq0, dptr(At), lda, ref)
+    end
     check(ctx, rc)
-    ls = HIPCholeskySolver{T}(ref[], ctx, Int32(0), opt_linear_solver, MadNLP.MadNLPLogger())
+    order = F == :augmented ? (cld(nx, 128) * 128 + m) : (F == :normal ? m : nx)
+    aug_com = HIPDenseKKTMatrix{T}(ref[], ctx, order, filter(!=(C_NULL), [jac_map, hess_map]))
+    ls = linear_solver(aug_com; opt = opt_linear_solver)             # src/KKT/normalkkt.jl:99-101
+    reg, pr_diag, du_diag = mk(n), mk(n), mk(m)
+    l_diag, u_diag, l_lower, u_lower = mk(nlb), mk(nub), mk(nlb), mk(nub)
+    ind_lb0, ind_ub0 = ind_cons.ind_lb .- 1, ind_cons.ind_ub .- 1
+    # the KKT's own view: everything build_kkt! / solve! / mul! read lives in the KKT object, so these three work
+    # from the first factorize_wrapper! on (src/solver.jl:16-21 calls it BEFORE any set_aug_diagonal_reg!)
+    cs = CState(n, m, nlb, nub, dptr(ind_lb0), dptr(ind_ub0),
+                NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF,
+                dptr(reg), dptr(pr_diag), dptr(du_diag), dptr(l_diag), dptr(l_lower), dptr(u_diag), dptr(u_lower))
     VI = typeof(ind_cons.ind_lb)
-    kkt = HIPCondensedKKTSystem{T, VT, typeof(H), MadNLP.ExactHessian{T, VT}, VI}(
-        ref[], ctx, H, At, mk(nx * m), mk(nx * nx),
-        mk(n), mk(n), mk(m), mk(nlb), mk(nub), mk(nlb), mk(nub), ls,
-        ind_ineq, ind_cons.ind_lb, ind_cons.ind_ub, ind_cons.ind_lb .- 1, ind_cons.ind_ub .- 1, n, m, nx)
+    kkt = HIPKKTSystem{T, VT, typeof(H), MadNLP.ExactHessian{T, VT}, VI, typeof(ls), F}(
+        aug_com, ref[], ctx, H, At, lda, mk(cb.nnzj), mk(cb.nnzh), jac_map, hess_map,
+        reg, pr_diag, du_diag, l_diag, u_diag, l_lower, u_lower, ls,
+        ind_ineq, ind_cons.ind_lb, ind_cons.ind_ub, ind_lb0, ind_ub0, Ref(cs), n, m, nx)
     return kkt
 end
 
-# The K2 form (MadNLP's default SparseKKTSystem, src/utils.jl:108) is the same glue with
-# `:madqp_kkt_create_augmented` in the ccall above (same argument list) -- the object then answers every
-# madqp_kkt_* call below as [H + Sigma_x, A'; A, -D] factorised L diag(I,-I) L'; its linear solver reports
-# inertia (nx, 0, m) and `is_inertia_correct(kkt, p, z, n) = (z == 0) && (n == kkt.m)`; equality rows need
-# no dual regularization (the reference's default FixedRegularization(1e-8, 0.0) works as is).
+for (TY, F) in ((:HIPCondensedKKTSystem, :condensed), (:HIPAugmentedKKTSystem, :augmented), (:HIPNormalKKTSystem, :normal))
+    @eval function MadNLP.create_kkt_system(
+        ::Type{$TY}, cb::MadNLP.SparseCallback{T, VT}, ind_cons, linear_solver::Type;
+        opt_linear_solver = MadNLP.default_options(linear_solver),
+        hessian_approximation = MadNLP.ExactHessian, qn_options = MadNLP.QuasiNewtonOptions(),
+    ) where {T, VT}
+        return _create($(QuoteNode(F)), cb, ind_cons, linear_solver, opt_linear_solver)
+    end
+end
 
-MadNLP.num_variables(kkt::HIPCondensedKKTSystem) = kkt.n
-MadNLP.get_jacobian(kkt::HIPCondensedKKTSystem) = kkt.jac
-MadNLP.get_hessian(kkt::HIPCondensedKKTSystem) = kkt.hess
-MadNLP.is_inertia_correct(kkt::HIPCondensedKKTSystem, p, z, n) = (z == 0) && (n == 0)
+MadNLP.num_variables(kkt::HIPKKTSystem) = kkt.n                 # src/KKT/normalkkt.jl:128
+MadNLP.get_jacobian(kkt::HIPKKTSystem) = kkt.jac                # :129 -- the nnzj buffer SparseCallback fills
+MadNLP.get_hessian(kkt::HIPKKTSystem) = kkt.hess                # :130
+function MadNLP.is_inertia_correct(kkt::HIPKKTSystem, num_pos, num_zero, num_neg)   # :132-134
+    form(kkt) == :augmented && return (num_zero == 0) && (num_neg == kkt.m)
+    return (num_zero == 0) && (num_pos == kkt.aug_com.order)
+end
 
-function MadNLP.initialize!(kkt::HIPCondensedKKTSystem{T}) where {T}      # src/KKT/normalkkt.jl:136-147
+function MadNLP.initialize!(kkt::HIPKKTSystem{T}) where {T}      # src/KKT/normalkkt.jl:136-147
     fill!(kkt.reg, one(T)); fill!(kkt.pr_diag, one(T)); fill!(kkt.du_diag, zero(T))
     fill!(kkt.l_lower, zero(T)); fill!(kkt.u_lower, zero(T))
     fill!(kkt.l_diag, one(T)); fill!(kkt.u_diag, one(T))
     return
 end
 
-# dense callbacks write row-major values: the Jacobian buffer IS A with row k contiguous, i.e. At
-MadNLP.compress_jacobian!(kkt::HIPCondensedKKTSystem) = copyto!(vec(kkt.At), kkt.jac)
-MadNLP.compress_hessian!(kkt::HIPCondensedKKTSystem) = copyto!(vec(kkt.H), kkt.hess)
-
-# state view for one solver: built once per MPCSolver and cached in a WeakKeyDict
-const STATES = WeakKeyDict{Any, CState}()
-function state(solver)
-    get!(STATES, solver) do
-        kkt = solver.kkt
-        CState(solver.n, solver.m, solver.nlb, solver.nub, dptr(kkt.ind_lb0), dptr(kkt.ind_ub0),
-               dptr(MadNLP.full(solver.x)), dptr(MadNLP.full(solver.xl)), dptr(MadNLP.full(solver.xu)),
-               dptr(MadNLP.full(solver.zl)), dptr(MadNLP.full(solver.zu)), dptr(MadNLP.full(solver.f)),
-               dptr(solver.y), dptr(solver.c), dptr(solver.jacl),
-               dptr(MadNLP.full(solver.d)), dptr(MadNLP.full(solver.p)),
-               dptr(solver.correction_lb), dptr(solver.correction_ub),
-               dptr(kkt.reg), dptr(kkt.pr_diag), dptr(kkt.du_diag),
-               dptr(kkt.l_diag), dptr(kkt.l_lower), dptr(kkt.u_diag), dptr(kkt.u_lower))
-    end
+# src/KKT/normalkkt.jl:149-158: callback values (COO order) -> the matrix storage.  The slack columns (-1) are implicit
+# in the library (ind_ineq), so only the nnzj model entries travel.
+function MadNLP.compress_jacobian!(kkt::HIPKKTSystem)
+    check(kkt.ctx, ccall((:madqp_coo_map_apply, libmadqp), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64),
+                         kkt.jac_map, dptr(kkt.jac), dptr(kkt.At), kkt.lda))
+    return
 end
-# solve!/mul! receive only the KKT object: the owning solver registers its state here
-const KKT_STATE = WeakKeyDict{Any, CState}()
-register!(solver) = (KKT_STATE[solver.kkt] = state(solver); solver)
+function MadNLP.compress_hessian!(kkt::HIPKKTSystem)
+    kkt.hess_map == C_NULL && return
+    check(kkt.ctx, ccall((:madqp_coo_map_apply, libmadqp), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64),
+                         kkt.hess_map, dptr(kkt.hess), dptr(kkt.H), max(kkt.nx, 1)))
+    return
+end
 
-function MadNLP.jtprod!(y::AbstractVector, kkt::HIPCondensedKKTSystem, x::AbstractVector)
+function MadNLP.jtprod!(y::AbstractVector, kkt::HIPKKTSystem, x::AbstractVector)   # :162-164
     check(kkt.ctx, ccall((:madqp_kkt_jtprod, libmadqp), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
                          kkt.handle, dptr(y), dptr(x)))
     return y
 end
 
-function MadNLP.build_kkt!(kkt::HIPCondensedKKTSystem)                  # src/KKT/normalkkt.jl:166-180
-    check(kkt.ctx, ccall((:madqp_kkt_build, libmadqp), Int32, (Ptr{Cvoid}, Ref{CState}), kkt.handle, KKT_STATE[kkt]))
+function MadNLP.build_kkt!(kkt::HIPKKTSystem)                  # src/KKT/normalkkt.jl:166-180
+    check(kkt.ctx, ccall((:madqp_kkt_build, libmadqp), Int32, (Ptr{Cvoid}, Ref{CState}), kkt.handle, kkt.cstate))
+    return
 end
 
-function MadNLP.solve!(kkt::HIPCondensedKKTSystem, w::MadNLP.AbstractKKTVector)   # :182-205
+function MadNLP.solve!(kkt::HIPKKTSystem, w::MadNLP.AbstractKKTVector)   # :182-205
     check(kkt.ctx, ccall((:madqp_kkt_solve, libmadqp), Int32, (Ptr{Cvoid}, Ref{CState}, Ptr{Float64}),
-                         kkt.handle, KKT_STATE[kkt], dptr(MadNLP.full(w))))
+                         kkt.handle, kkt.cstate, dptr(MadNLP.full(w))))
     return w
 end
 
-function LinearAlgebra.mul!(w::MadNLP.AbstractKKTVector{T}, kkt::HIPCondensedKKTSystem,
-                            v::MadNLP.AbstractKKTVector, alpha = one(T), beta = zero(T)) where {T}   # :207-219
+function mul!(w::MadNLP.AbstractKKTVector{T}, kkt::HIPKKTSystem, v::MadNLP.AbstractKKTVector,
+              alpha = one(T), beta = zero(T)) where {T}           # :207-219
     check(kkt.ctx, ccall((:madqp_kkt_mul, libmadqp), Int32,
                          (Ptr{Cvoid}, Ref{CState}, Ptr{Float64}, Ptr{Float64}, Float64, Float64),
-                         kkt.handle, KKT_STATE[kkt], dptr(MadNLP.full(w)), dptr(MadNLP.full(v)), alpha, beta))
+                         kkt.handle, kkt.cstate, dptr(MadNLP.full(w)), dptr(MadNLP.full(v)), alpha, beta))
     return w
 end
 
 # --------------------------------------------------------------------------- src/kernels.jl on the device
+# full state view of one solver (iterates + the KKT's diagonals), built on first use
+const STATES = WeakKeyDict{Any, Base.RefValue{CState}}()
+function state(solver)
+    get!(STATES, solver) do
+        kkt = solver.kkt
+        Ref(CState(solver.n, solver.m, solver.nlb, solver.nub, dptr(kkt.ind_lb0), dptr(kkt.ind_ub0),
+                   dptr(MadNLP.full(solver.x)), dptr(MadNLP.full(solver.xl)), dptr(MadNLP.full(solver.xu)),
+                   dptr(MadNLP.full(solver.zl)), dptr(MadNLP.full(solver.zu)), dptr(MadNLP.full(solver.f)),
+                   dptr(solver.y), dptr(solver.c), dptr(solver.jacl),
+                   dptr(MadNLP.full(solver.d)), dptr(MadNLP.full(solver.p)),
+                   dptr(solver.correction_lb), dptr(solver.correction_ub),
+                   dptr(kkt.reg), dptr(kkt.pr_diag), dptr(kkt.du_diag),
+                   dptr(kkt.l_diag), dptr(kkt.l_lower), dptr(kkt.u_diag), dptr(kkt.u_lower)))
+    end
+end
+
 macro k(name, argtypes, args...)
     esc(:(check(solver.kkt.ctx, ccall(($(QuoteNode(name)), libmadqp), Int32,
                                       (Ptr{Cvoid}, Ref{CState}, $(argtypes.args...)),
                                       solver.kkt.ctx.ptr, state(solver), $(args...)))))
 end
-const HIPSolver = MadIPM.MPCSolver{T, VT, VI, <:HIPCondensedKKTSystem} where {T, VT, VI}
+const HIPSolver = MadIPM.MPCSolver{T, VT, VI, K} where {T, VT, VI, K <: HIPKKTSystem}
 
-function MadIPM.set_aug_diagonal_reg!(kkt::HIPCondensedKKTSystem, solver::MadNLP.AbstractMadNLPSolver)   # kernels.jl:128-146
-    register!(solver)
+function MadIPM.set_aug_diagonal_reg!(kkt::HIPKKTSystem{T}, solver::MadNLP.AbstractMadNLPSolver{T}) where {T}   # kernels.jl:128-146
     @k madqp_set_aug_diagonal_reg (Float64, Float64) solver.del_w solver.del_c
 end
 MadIPM.set_initial_primal_rhs!(solver::HIPSolver) = @k madqp_set_initial_primal_rhs ()
 MadIPM.set_initial_dual_rhs!(solver::HIPSolver) = @k madqp_set_initial_dual_rhs ()
-MadIPM.set_predictive_rhs!(solver::MadNLP.AbstractMadNLPSolver, ::HIPCondensedKKTSystem) = @k madqp_set_predictive_rhs ()
-MadIPM.set_correction_rhs!(solver::MadNLP.AbstractMadNLPSolver, ::HIPCondensedKKTSystem, mu::Float64, clb, cub, ilb, iub) =
+MadIPM.set_predictive_rhs!(solver::MadNLP.AbstractMadNLPSolver, ::HIPKKTSystem) = @k madqp_set_predictive_rhs ()
+MadIPM.set_correction_rhs!(solver::MadNLP.AbstractMadNLPSolver, ::HIPKKTSystem, mu::Float64,
+                           clb::AbstractVector{Float64}, cub::AbstractVector{Float64}, ilb, iub) =
     @k madqp_set_correction_rhs (Float64,) mu
 MadIPM.get_correction!(solver::HIPSolver, clb, cub) = @k madqp_get_correction ()
 MadIPM.set_extra_correction!(solver::HIPSolver, clb, cub, ap, ad, bmin, bmax, mu) =
@@ -234,9 +343,10 @@ function MadIPM.get_fraction_to_boundary_step(solver::HIPSolver, tau)      # ker
     return min(a[1], a[2]), min(a[3], a[4])
 end
 
-# The four axpy! of src/solver.jl:332-335, MadNLP.adjust_boundary! (:342) and the residual norms of
-# :264-272 are reached the same way (madqp_update_iterates, madqp_adjust_boundary, madqp_get_inf); they
-# are plain broadcasts over ROCArrays in the reference and need no override to be correct, only to
-# be fused.  INTEGRATION.md lists the remaining optional bindings.
+# The four axpy! of src/solver.jl:332-335, MadNLP.adjust_boundary! (:342), the residual norms of :264-272 and the
+# map!/mapreduce of init_starting_point! (:41-123) are plain broadcasts over the solver's ROCArrays in the reference:
+# they need no override to be correct, only to be fused (madqp_update_iterates, madqp_adjust_boundary, madqp_get_inf,
+# madqp_sp_*).  MehrotraAdaptiveStep's scalar reads (src/kernels.jl:349-369) need `AMDGPU.@allowscalar` as they do
+# with CUDA.  INTEGRATION.md lists these optional bindings.
 
 end # module

@@ -131,6 +131,9 @@ _SIGNATURES = {
     "madqp_kkt_matrix": [vp, C.POINTER(vp), pi64],
     "madqp_kkt_create_sparse": [vp, i32, i64, i64, i64, pi64, vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
     "madqp_kkt_set_hdiag": [vp, vp],
+    "madqp_coo_map_create": [vp, i64, vp, vp, i64, i64, i32, C.POINTER(vp)],
+    "madqp_coo_map_apply": [vp, vp, vp, i64],
+    "madqp_coo_map_destroy": [vp],
     "madqp_syrk_assemble_cols": [vp, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, i64, pi64],
     "madqp_kkt_build_cols": [vp, pstate, i64, pi64],
     "madqp_kkt_chol": [vp, C.POINTER(vp), pi64],

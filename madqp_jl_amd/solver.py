@@ -314,6 +314,31 @@ class MPCSolver:
         if not be.sp_check(st):  # :120-123
             raise AssertionError("starting point is not strictly interior")
 
+    def _create_kkt_system(self):
+        """``MadNLP.create_kkt_system(opt.kkt_system, cb, ind_cons, opt.linear_solver)`` (src/structure.jl:115-121) on
+        the scaled model data; a seam for tests that swap the plugin types."""
+        opt, be, st, nx = self.opt, self.be, self.st, self.nx
+        extra = {}
+        if opt.distributed:  # SURVEY.md 8e: one KKT system over the ranks of the default process group
+            from . import dist as D
+
+            normal_cls, condensed_cls = D.HIPDistributedNormalKKTSystem, D.HIPDistributedCondensedKKTSystem
+            extra = dict(panel_width=opt.panel_width)
+        else:
+            normal_cls, condensed_cls = HIPNormalKKTSystem, HIPCondensedKKTSystem
+        if isinstance(self.A, DeviceCSR):  # sparse front end: dense K / Cholesky, CSR products
+            if opt.distributed:
+                raise ValueError("the sparse front end runs on one GPU")
+            cls = {"normal": HIPSparseNormalKKTSystem, "augmented": HIPSparseAugmentedKKTSystem,
+                   "condensed": HIPSparseCondensedKKTSystem}[opt.kkt_system]
+            return cls(be, st, nx, self.ind_ineq, self.H, self.A)
+        if opt.kkt_system == "augmented":
+            return HIPAugmentedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)
+        if opt.kkt_system == "normal":
+            self.At = self.A.t().contiguous()  # (nx, m): the layout the normal-equations GEMM consumes
+            return normal_cls(be, st, nx, self.ind_ineq, self.H, self.At, **extra)
+        return condensed_cls(be, st, nx, self.ind_ineq, self.H, self.A, **extra)
+
     def initialize(self):  # :127-182
         qp, opt, st, be = self.qp, self.opt, self.st, self.be
         nx, dev = self.nx, st.device
@@ -363,27 +388,7 @@ class MPCSolver:
             self._fact_closed += self.kkt.n_factorizations
             self.kkt.close()
             self.kkt = None
-        extra = {}
-        if opt.distributed:  # one KKT system over the ranks of the default process group
-            from . import dist as D
-
-            normal_cls, condensed_cls = D.HIPDistributedNormalKKTSystem, D.HIPDistributedCondensedKKTSystem
-            extra = dict(panel_width=opt.panel_width)
-        else:
-            normal_cls, condensed_cls = HIPNormalKKTSystem, HIPCondensedKKTSystem
-        if isinstance(self.A, DeviceCSR):  # sparse front end: dense K / Cholesky, CSR products
-            if opt.distributed:
-                raise ValueError("the sparse front end runs on one GPU")
-            cls = {"normal": HIPSparseNormalKKTSystem, "augmented": HIPSparseAugmentedKKTSystem,
-                   "condensed": HIPSparseCondensedKKTSystem}[opt.kkt_system]
-            self.kkt = cls(be, st, nx, self.ind_ineq, self.H, self.A)
-        elif opt.kkt_system == "augmented":
-            self.kkt = HIPAugmentedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)
-        elif opt.kkt_system == "normal":
-            self.At = self.A.t().contiguous()  # (nx, m): the layout the normal-equations GEMM consumes
-            self.kkt = normal_cls(be, st, nx, self.ind_ineq, self.H, self.At, **extra)
-        else:
-            self.kkt = condensed_cls(be, st, nx, self.ind_ineq, self.H, self.A, **extra)
+        self.kkt = self._create_kkt_system()
         self.kkt.initialize()  # :162
         self.init_regularization()  # :163
         self.eval_model()  # :166-169
