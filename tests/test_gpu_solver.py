@@ -341,13 +341,17 @@ def test_batch_of_independent_qps(hip):
 
 
 def test_full_size_c_main_properties(hip):
-    """BASELINE metric size (n_x = 50 000, m = 20 000): far beyond the oracle, so size-independent
+    torch.cuda.empty_cache()
+    full_size_properties(hip, 50000, 20000, 20250614 + 1)
+
+
+def full_size_properties(hip, nx, m, seed):
+    """BASELINE metric size (n_x = 50 000, m = 20 000; also configs[4], tests/test_gpu_configs.py): far beyond the oracle, so size-independent
     properties through the same C ABI: (a) the on-device generator reproduces randomly chosen tiles of
     A, H and q bit for bit; (b) the assembled condensed K equals H + Sigma + A' Theta A on sampled
     entries; (c) the factorisation succeeds and every solve_system! of two IPM iterations (condense,
     two triangular sweeps, decondense) satisfies the UNREDUCED KKT system (residual through mul!);
     the iteration makes progress."""
-    nx, m, seed = 50000, 20000, 20250614 + 1
     dq = M.DeviceQP.synthetic(hip, seed, nx, m)
     rng = np.random.default_rng(0)
     # (a) generator tiles
@@ -397,4 +401,6 @@ def test_full_size_c_main_properties(hip):
         assert s.last_residual_ratio < 1e-7, s.last_residual_ratio
         assert s.iteration_head() is None
     assert s.inf_pr < pr0 and 0 < s.alpha_p <= 1 and 0 < s.alpha_d <= 1
-    s.kkt.close()
+    s.close()
+    del s, dq
+    torch.cuda.empty_cache()
