@@ -60,9 +60,92 @@ def parse():
                         "pure throughput of small problems, whose factorisation is replayed as a hipGraph only when "
                         "no events sit between its launches")
     p.add_argument("--cpu-sample-nx", type=int, default=8000)
+    p.add_argument("--cpu-full", action="store_true",
+                   help="only the CPU port at the FULL workload size: initialize + one iteration, timed (minutes); "
+                        "prints its own JSON line -- kept under profiles/ and quoted by the default run")
     p.add_argument("--profile-all", action="store_true", help="time every kernel class (perturbs the "
                    "launch-bound ones); default times only the MFMA classes")
     return p.parse_args()
+
+
+def host_cores():
+    """Threads the CPU legs use = the cores this process may run on: the affinity mask, cut to the cgroup's CPU quota
+    when one is set (a GPU box hands one GPU's job a share of the host).  MADQP_CPU_THREADS overrides."""
+    if os.environ.get("MADQP_CPU_THREADS"):
+        return max(1, int(os.environ["MADQP_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_full_size(args, M, be):
+    """SURVEY.md 8d / BASELINE.md section 3: the CPU port timed AT the metric size -- set-up with its start-point
+    factorisation and two solves (src/solver.jl:127-182) and one full iteration (:259-343) of oracle/mpc.py on the
+    same inputs bit for bit (generated on the device, copied to the host).  Takes minutes: run on its own
+    (`python bench.py --cpu-full`), the result is kept under profiles/ and quoted by the default run."""
+    import numpy as np
+    import torch
+
+    from oracle import mpc
+    from oracle import qp as Q
+
+    nx, m = args.nx, args.m
+    cores = host_cores()
+    try:
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(limits=cores)
+    except Exception:
+        pass
+    note = lambda msg: print(f"[cpu-full {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+    dq = M.DeviceQP.synthetic(be, args.seed, nx, m)
+    h = lambda t: t.cpu().numpy()
+    qp = Q.DenseQP(H=h(dq.H), q=h(dq.q), A=h(dq.A), lvar=h(dq.lvar), uvar=h(dq.uvar), lcon=h(dq.lcon),
+                   ucon=h(dq.ucon), x0=h(dq.x0))
+    del dq
+    torch.cuda.empty_cache()
+    note(f"inputs on the host (nx={nx}, m={m}), {cores} BLAS threads")
+    s = mpc.MPCSolver(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8),
+                      step_rule=mpc.AdaptiveStep(0.995), mu_min=1e-12, max_iter=300, max_ncorr=args.max_ncorr)
+    t0 = time.perf_counter()
+    s.initialize()
+    t_init = time.perf_counter() - t0
+    note(f"initialize (start-point factorisation + 2 solves): {t_init:.1f} s")
+    s.iteration_head()
+    t0 = time.perf_counter()
+    s.iteration_body()
+    s.iteration_head()
+    t_iter = time.perf_counter() - t0
+    note(f"one iteration: {t_iter:.1f} s")
+    flops = m * nx * nx + nx ** 3 / 3.0
+    return dict(value=1.0 / t_iter, unit="IPM iterations/s", cores=cores, kind="port", nx=nx, m=m,
+                max_ncorr=args.max_ncorr, seconds_per_iteration=t_iter, seconds_initialize=t_init,
+                algorithmic_tflops=flops / t_iter * 1e-12, n_factorizations=s.kkt.n_factorizations,
+                sample=f"oracle/mpc.py (numpy + scipy LAPACK, {cores} BLAS threads) at the metric size nx={nx}, m={m}: "
+                       f"initialize {t_init:.1f} s, one full iteration {t_iter:.1f} s; no extrapolation",
+                trace=[{k: float(t[k]) for k in ("k", "inf_pr", "inf_du", "inf_compl", "mu", "alpha_p", "alpha_d")}
+                       for t in s.trace])
+
+
+def cpu_full_size_record(nx, m):
+    """The committed result of `bench.py --cpu-full` for this workload (profiles/*cpu_fullsize*.json), if any."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cpu_fullsize*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("nx") == nx and d.get("m") == m:
+                d = {k: d[k] for k in d if k != "trace"}
+                d["source"] = os.path.basename(f)
+                return d
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(args, nx, m):
@@ -73,8 +156,7 @@ def cpu_baseline(args, nx, m):
     from oracle import mpc
     from oracle import qp as Q
 
-    # BLAS threads: the box's CPU share for one GPU is 16 cores (its affinity mask shows all of them)
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores = host_cores()
     try:
         from threadpoolctl import threadpool_limits
 
@@ -102,7 +184,7 @@ def cpu_baseline(args, nx, m):
     sn, sm, iters, dt, scale = sample(min(args.cpu_sample_nx, nx), 12.0, 50)
     out = dict(
         value=(iters / dt) * scale, unit="IPM iterations/s", cores=cores, kind="port",
-        sample=(f"oracle/mpc.py (numpy+scipy LAPACK, {cores} BLAS threads = the box's CPU share) on the same synthetic "
+        sample=(f"oracle/mpc.py (numpy+scipy LAPACK, {cores} BLAS threads) on the same synthetic "
                 f"family at nx={sn}, m={sm}: {iters} iterations in {dt:.2f} s = {iters / dt:.3f} it/s, "
                 f"scaled by the flop ratio (m nx^2 + nx^3/3) {scale:.3e} to nx={nx}, m={m}"),
         measured_it_per_s_at_sample=iters / dt, sample_nx=sn, sample_m=sm)
@@ -114,6 +196,9 @@ def cpu_baseline(args, nx, m):
         threadpool_limits(limits=cores)
     except Exception as e:
         out["single_thread"] = {"error": str(e)[:200]}
+    full = cpu_full_size_record(nx, m)
+    if full is not None:  # measured once at the metric size on a GPU box's host (minutes of CPU time): no extrapolation
+        out["measured_at_metric_size"] = full
     return out
 
 
@@ -281,6 +366,10 @@ def main():
 
     be = M.HipBackend(local_rank)
     nx, m = args.nx, args.m
+    if args.cpu_full:
+        print(json.dumps(cpu_full_size(args, M, be)), flush=True)
+        be.close()
+        return
     shared = args.kkt == "distributed"
     res = measure(args, M, be, world, args.seed if shared else rank_seed(args.seed, rank), shared)
     tmax, prof, nfact = res["tmax"], res["prof"], res["nfact"]

@@ -242,7 +242,20 @@ int32_t madqp_kkt_create_normal(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t n
 int32_t madqp_kkt_create_augmented(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
                                    const int64_t* ind_ineq_host, const double* H, int64_t ldh,
                                    const double* A, int64_t lda, madqp_kkt** out);
+/* K2.5: MadNLP's ScaledSparseKKTSystem as MadIPM drives it (set_aug_diagonal_reg! src/kernels.jl:149-165, the scaling
+ * of the augmented matrix scripts/cuda_wrapper.jl:90-116, K2.5 == K2 in test/runtests.jl:95-115) on the dense
+ * quasi-definite path: the matrix of madqp_kkt_create_augmented scaled symmetrically by sqrt((x - xl)(xu - x)) per
+ * variable, with l_diag = x - xl > 0, u_diag = xu - x > 0 and pr_diag = scaling^2 (del_w + Sigma).  The per-variable
+ * state must be set through madqp_kkt_set_aug_diagonal_reg / madqp_kkt_initialize. */
+int32_t madqp_kkt_create_scaled_augmented(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
+                                          const int64_t* ind_ineq_host, const double* H, int64_t ldh,
+                                          const double* A, int64_t lda, madqp_kkt** out);
 int32_t madqp_kkt_destroy(madqp_kkt* kkt);
+/* set_aug_diagonal_reg!(kkt, solver) dispatched on the KKT type, as the reference does (src/kernels.jl:128 for any
+ * AbstractKKTSystem = madqp_set_aug_diagonal_reg; :149 for ScaledSparseKKTSystem, with MadNLP._set_aug_diagonal!) */
+int32_t madqp_kkt_set_aug_diagonal_reg(madqp_kkt* kkt, const madqp_state* st, double del_w, double del_c);
+/* MadNLP.initialize!(kkt) (src/KKT/normalkkt.jl:136-147; K2.5: also scaling factor = 1) */
+int32_t madqp_kkt_initialize(madqp_kkt* kkt, const madqp_state* st);
 /* MadNLP.build_kkt! (src/KKT/normalkkt.jl:166-180): Theta from pr_diag/du_diag, then the SYRK */
 int32_t madqp_kkt_build(madqp_kkt* kkt, const madqp_state* st);
 /* MadNLP.factorize!(kkt.linear_solver); info as madqp_chol_factor */

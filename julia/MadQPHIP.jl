@@ -129,6 +129,8 @@ end
 # --------------------------------------------------------------------------- KKT system
 # F = :condensed  K = H + Sigma_x + A' Theta A            (madqp_kkt_create)
 #     :augmented  [H + Sigma_x, A'; A, -D], L diag(I,-I) L' (madqp_kkt_create_augmented; MadNLP's default K2 form)
+#     :scaled_augmented  the same matrix scaled symmetrically (madqp_kkt_create_scaled_augmented; MadNLP's K2.5,
+#                 ScaledSparseKKTSystem: src/kernels.jl:149-165, test/runtests.jl:95-115)
 #     :normal     A Sigma^-1 A', LP only                  (madqp_kkt_create_normal; the reference's NormalKKTSystem)
 struct HIPKKTSystem{T, VT, MT, QN, VI, LS, F} <: MadNLP.AbstractKKTSystem{T, VT, MT, QN}
     aug_com::HIPDenseKKTMatrix{T}
@@ -153,6 +155,7 @@ struct HIPKKTSystem{T, VT, MT, QN, VI, LS, F} <: MadNLP.AbstractKKTSystem{T, VT,
 end
 const HIPCondensedKKTSystem = HIPKKTSystem{T, VT, MT, QN, VI, LS, :condensed} where {T, VT, MT, QN, VI, LS}
 const HIPAugmentedKKTSystem = HIPKKTSystem{T, VT, MT, QN, VI, LS, :augmented} where {T, VT, MT, QN, VI, LS}
+const HIPScaledAugmentedKKTSystem = HIPKKTSystem{T, VT, MT, QN, VI, LS, :scaled_augmented} where {T, VT, MT, QN, VI, LS}
 const HIPNormalKKTSystem = HIPKKTSystem{T, VT, MT, QN, VI, LS, :normal} where {T, VT, MT, QN, VI, LS}
 form(::HIPKKTSystem{T, VT, MT, QN, VI, LS, F}) where {T, VT, MT, QN, VI, LS, F} = F
 
@@ -201,13 +204,17 @@ function _create(F::Symbol, cb::MadNLP.SparseCallback{T, VT}, ind_cons, linear_s
         rc = ccall((:madqp_kkt_create_augmented, libmadqp), Int32,
                    (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ref{Ptr{Cvoid}}),
                    ctx.ptr, nx, m, ns, ineq0, Hp, max(nx, 1), dptr(At), lda, ref)
+    elseif F == :scaled_augmented
+        rc = ccall((:madqp_kkt_create_scaled_augmented, libmadqp), Int32,
+                   (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ref{Ptr{Cvoid}}),
+                   ctx.ptr, nx, m, ns, ineq0, Hp, max(nx, 1), dptr(At), lda, ref)
     else   # A' with variable k contiguous = a Julia m x nx matrix as it stands
         rc = ccall((:madqp_kkt_create_normal, libmadqp), Int32,
                    (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Ptr{Cvoid}}),
                    ctx.ptr, nx, m, ns, ineq0, dptr(At), lda, ref)
     end
     check(ctx, rc)
-    order = F == :augmented ? (cld(nx, 128) * 128 + m) : (F == :normal ? m : nx)
+    order = (F == :augmented || F == :scaled_augmented) ? (cld(nx, 128) * 128 + m) : (F == :normal ? m : nx)
     aug_com = HIPDenseKKTMatrix{T}(ref[], ctx, order, filter(!=(C_NULL), [jac_map, hess_map]))
     ls = linear_solver(aug_com; opt = opt_linear_solver)             # src/KKT/normalkkt.jl:99-101
     reg, pr_diag, du_diag = mk(n), mk(n), mk(m)
@@ -226,7 +233,8 @@ function _create(F::Symbol, cb::MadNLP.SparseCallback{T, VT}, ind_cons, linear_s
     return kkt
 end
 
-for (TY, F) in ((:HIPCondensedKKTSystem, :condensed), (:HIPAugmentedKKTSystem, :augmented), (:HIPNormalKKTSystem, :normal))
+for (TY, F) in ((:HIPCondensedKKTSystem, :condensed), (:HIPAugmentedKKTSystem, :augmented),
+                (:HIPScaledAugmentedKKTSystem, :scaled_augmented), (:HIPNormalKKTSystem, :normal))
     @eval function MadNLP.create_kkt_system(
         ::Type{$TY}, cb::MadNLP.SparseCallback{T, VT}, ind_cons, linear_solver::Type;
         opt_linear_solver = MadNLP.default_options(linear_solver),
@@ -240,14 +248,12 @@ MadNLP.num_variables(kkt::HIPKKTSystem) = kkt.n                 # src/KKT/normal
 MadNLP.get_jacobian(kkt::HIPKKTSystem) = kkt.jac                # :129 -- the nnzj buffer SparseCallback fills
 MadNLP.get_hessian(kkt::HIPKKTSystem) = kkt.hess                # :130
 function MadNLP.is_inertia_correct(kkt::HIPKKTSystem, num_pos, num_zero, num_neg)   # :132-134
-    form(kkt) == :augmented && return (num_zero == 0) && (num_neg == kkt.m)
+    form(kkt) in (:augmented, :scaled_augmented) && return (num_zero == 0) && (num_neg == kkt.m)
     return (num_zero == 0) && (num_pos == kkt.aug_com.order)
 end
 
-function MadNLP.initialize!(kkt::HIPKKTSystem{T}) where {T}      # src/KKT/normalkkt.jl:136-147
-    fill!(kkt.reg, one(T)); fill!(kkt.pr_diag, one(T)); fill!(kkt.du_diag, zero(T))
-    fill!(kkt.l_lower, zero(T)); fill!(kkt.u_lower, zero(T))
-    fill!(kkt.l_diag, one(T)); fill!(kkt.u_diag, one(T))
+function MadNLP.initialize!(kkt::HIPKKTSystem{T}) where {T}      # src/KKT/normalkkt.jl:136-147 (+ K2.5's scaling factor)
+    check(kkt.ctx, ccall((:madqp_kkt_initialize, libmadqp), Int32, (Ptr{Cvoid}, Ref{CState}), kkt.handle, kkt.cstate))
     return
 end
 
@@ -314,8 +320,11 @@ macro k(name, argtypes, args...)
 end
 const HIPSolver = MadIPM.MPCSolver{T, VT, VI, K} where {T, VT, VI, K <: HIPKKTSystem}
 
-function MadIPM.set_aug_diagonal_reg!(kkt::HIPKKTSystem{T}, solver::MadNLP.AbstractMadNLPSolver{T}) where {T}   # kernels.jl:128-146
-    @k madqp_set_aug_diagonal_reg (Float64, Float64) solver.del_w solver.del_c
+# kernels.jl:128-146, and :149-165 for the K2.5 form: the library dispatches on the KKT object
+function MadIPM.set_aug_diagonal_reg!(kkt::HIPKKTSystem{T}, solver::MadNLP.AbstractMadNLPSolver{T}) where {T}
+    check(kkt.ctx, ccall((:madqp_kkt_set_aug_diagonal_reg, libmadqp), Int32, (Ptr{Cvoid}, Ref{CState}, Float64, Float64),
+                         kkt.handle, state(solver), solver.del_w, solver.del_c))
+    return
 end
 MadIPM.set_initial_primal_rhs!(solver::HIPSolver) = @k madqp_set_initial_primal_rhs ()
 MadIPM.set_initial_dual_rhs!(solver::HIPSolver) = @k madqp_set_initial_dual_rhs ()

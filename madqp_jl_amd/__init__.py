@@ -10,7 +10,7 @@ from ._lib import EXPORTED_SYMBOLS, LIB_PATH, MadQPError, load_cdll
 from .backend import HipBackend, State
 from .batch import shard, solve_batch
 from .batched import BatchedMPCSolver
-from .kkt import (HIPAugmentedKKTSystem, HIPCholeskySolver, HIPCondensedKKTSystem, HIPNormalKKTSystem, HIPSparseAugmentedKKTSystem, HIPSparseCondensedKKTSystem,
+from .kkt import (HIPScaledAugmentedKKTSystem, HIPAugmentedKKTSystem, HIPCholeskySolver, HIPCondensedKKTSystem, HIPNormalKKTSystem, HIPSparseAugmentedKKTSystem, HIPSparseCondensedKKTSystem,
                   HIPSparseNormalKKTSystem)
 from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, FixedRegularization,
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
@@ -19,7 +19,7 @@ from .solver import (ERROR_IN_STEP_COMPUTATION, MAXIMUM_ITERATIONS_EXCEEDED, SOL
                      MPCSolver, SolveException, solve)
 
 __all__ = [
-    "HipBackend", "State", "shard", "solve_batch", "BatchedMPCSolver", "solve", "HIPCholeskySolver", "HIPAugmentedKKTSystem", "HIPCondensedKKTSystem", "HIPNormalKKTSystem", "HIPSparseAugmentedKKTSystem", "HIPSparseCondensedKKTSystem", "HIPSparseNormalKKTSystem", "MPCSolver", "DeviceQP",
+    "HipBackend", "State", "shard", "solve_batch", "BatchedMPCSolver", "solve", "HIPCholeskySolver", "HIPAugmentedKKTSystem", "HIPScaledAugmentedKKTSystem", "HIPCondensedKKTSystem", "HIPNormalKKTSystem", "HIPSparseAugmentedKKTSystem", "HIPSparseCondensedKKTSystem", "HIPSparseNormalKKTSystem", "MPCSolver", "DeviceQP",
     "DeviceCSR",
     "IPMOptions", "AdaptiveStep", "ConservativeStep", "MehrotraAdaptiveStep", "NoRegularization",
     "FixedRegularization", "AdaptiveRegularization", "MadQPError", "SolveException", "load_cdll",

@@ -121,7 +121,10 @@ _SIGNATURES = {
     "madqp_kkt_create": [vp, i64, i64, i64, pi64, vp, i64, vp, i64, C.POINTER(vp)],
     "madqp_kkt_create_normal": [vp, i64, i64, i64, pi64, vp, i64, C.POINTER(vp)],
     "madqp_kkt_create_augmented": [vp, i64, i64, i64, pi64, vp, i64, vp, i64, C.POINTER(vp)],
+    "madqp_kkt_create_scaled_augmented": [vp, i64, i64, i64, pi64, vp, i64, vp, i64, C.POINTER(vp)],
     "madqp_kkt_destroy": [vp],
+    "madqp_kkt_set_aug_diagonal_reg": [vp, pstate, f64, f64],
+    "madqp_kkt_initialize": [vp, pstate],
     "madqp_kkt_build": [vp, pstate],
     "madqp_kkt_factorize": [vp, pi32],
     "madqp_kkt_solve": [vp, pstate, vp],

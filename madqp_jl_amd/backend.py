@@ -287,6 +287,20 @@ class HipBackend:
         self._ck(self.lib.madqp_kkt_create_augmented(self.ctx, nx, m, ns, arr, ptr(H), ldh, ptr(A), lda, C.byref(h)))
         return h
 
+    def kkt_create_scaled_augmented(self, nx, m, ind_ineq, H, ldh, A, lda):
+        ns = len(ind_ineq)
+        arr = (C.c_int64 * max(ns, 1))(*[int(i) for i in ind_ineq])
+        h = C.c_void_p()
+        self._ck(self.lib.madqp_kkt_create_scaled_augmented(self.ctx, nx, m, ns, arr, ptr(H), ldh, ptr(A), lda,
+                                                            C.byref(h)))
+        return h
+
+    def kkt_set_aug_diagonal_reg(self, h, st, del_w, del_c):
+        self._ck(self.lib.madqp_kkt_set_aug_diagonal_reg(h, C.byref(st.cstruct), del_w, del_c))
+
+    def kkt_initialize(self, h, st):
+        self._ck(self.lib.madqp_kkt_initialize(h, C.byref(st.cstruct)))
+
     def kkt_create_normal(self, nx, m, ind_ineq, At, ldat):
         ns = len(ind_ineq)
         arr = (C.c_int64 * max(ns, 1))(*[int(i) for i in ind_ineq])

@@ -19,6 +19,14 @@
 // nx + m.  It is quasi-definite, so L diag(I, -I) L' without pivoting is stable (madqp_chol_set_signature), and
 // equality rows need no dual regularization when A_eq has full row rank:
 //   [H + Sigma_x, A'; A, -D] [dx; dy] = [r1_x; r2 + r1_s / S],   ds = (r1_s + dy) / S
+//
+// Mode AUGMENTED with `scaled` set is K2.5, MadNLP's ScaledSparseKKTSystem as MadIPM drives it (src/kernels.jl:149-165;
+// test/runtests.jl:95-115): l_diag = x - xl > 0, u_diag = xu - x > 0 (signs flipped against K2), a_j = l_diag or 1,
+// b_j = u_diag or 1,  scaling_j = sqrt(a_j b_j),  pr_diag_j = zl_j b_j + zu_j a_j + dw a_j b_j = scaling^2 (dw + Sigma).
+// The matrix is the symmetric scaling of K2 entry by entry as scripts/cuda_wrapper.jl:90-116 does it for the COO
+// values -- pr_diag as it stands, Hessian entries times scaling_i scaling_j, Jacobian entries times scaling_j, du_diag
+// as it stands -- with the slack block eliminated as in the unscaled case (1/S_k becomes scaling_k^2 / pr_diag_k):
+// every entry stays bounded as the iterates converge.
 #include <algorithm>
 
 #include "common.h"
@@ -51,6 +59,8 @@ struct madqp_kkt {
     double *theta, *t, *u;  // m
     int64_t np;             // augmented mode: nx rounded up to a multiple of 128 = row of the first constraint
     double* b;              // augmented mode: right-hand side of order np + m
+    int scaled;             // augmented mode: K2.5 (see the header comment)
+    double *sfac, *sb;      // K2.5: scaling factor (n) and a scratch n-vector
     madqp_chol* chol;
 };
 
@@ -72,6 +82,7 @@ __global__ __launch_bounds__(256) void aug_fill_kernel(int64_t nx, int64_t np, i
                                                        int64_t ldh, const double* __restrict__ hdiag,
                                                        const double* __restrict__ dx, const double* __restrict__ A,
                                                        int64_t lda, const double* __restrict__ dd,
+                                                       const double* __restrict__ sf,  // K2.5 scaling or nullptr
                                                        double* __restrict__ K, int64_t ldk) {
     const int64_t ti = blockIdx.x, tj = blockIdx.y;
     if (tj > ti) return;
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256) void aug_fill_kernel(int64_t nx, int64_t np, i
         const int64_t r0 = i0 - np;
         for (int rr = ty; rr < 64; rr += 4) {
             const int64_t r = r0 + rr, j = j0 + tx;
-            tile[rr][tx] = (r < m && j < nx) ? A[r * lda + j] : 0.0;
+            tile[rr][tx] = (r < m && j < nx) ? (sf ? A[r * lda + j] * sf[j] : A[r * lda + j]) : 0.0;
         }
         __syncthreads();
         const int64_t i = i0 + tx;
@@ -103,8 +114,8 @@ __global__ __launch_bounds__(256) void aug_fill_kernel(int64_t nx, int64_t np, i
         if (j > i) continue;
         double v = 0.0;
         if (i < nx) {
-            if (H) v = H[i + j * ldh];
-            if (i == j) v += dx[i] + (hdiag ? hdiag[i] : 0.0);
+            if (H) v = sf ? H[i + j * ldh] * sf[i] * sf[j] : H[i + j * ldh];
+            if (i == j) v += dx[i] + (hdiag ? (sf ? hdiag[i] * sf[i] * sf[i] : hdiag[i]) : 0.0);
         } else if (i == j) {
             v = (i < np) ? 1.0 : dd[i - np];
         }
@@ -115,11 +126,104 @@ __global__ __launch_bounds__(256) void aug_fill_kernel(int64_t nx, int64_t np, i
 // sparse Jacobian (CSR of A): K[np + r, col] = val, 16 lanes per row
 __global__ __launch_bounds__(256) void aug_scatter_kernel(int64_t m, int64_t np, const int64_t* __restrict__ ptr,
                                                           const int64_t* __restrict__ col,
-                                                          const double* __restrict__ val, double* __restrict__ K,
+                                                          const double* __restrict__ val,
+                                                          const double* __restrict__ sf, double* __restrict__ K,
                                                           int64_t ldk) {
     const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     if (r >= m) return;
-    for (int64_t e = ptr[r] + (threadIdx.x & 15); e < ptr[r + 1]; e += 16) K[(np + r) + col[e] * ldk] = val[e];
+    for (int64_t e = ptr[r] + (threadIdx.x & 15); e < ptr[r + 1]; e += 16)
+        K[(np + r) + col[e] * ldk] = sf ? val[e] * sf[col[e]] : val[e];
+}
+
+// ---- K2.5 (scaled augmented system): set_aug_diagonal_reg!(::ScaledSparseKKTSystem) (src/kernels.jl:149-165) with
+// MadNLP._set_aug_diagonal! folded in, and the sign-flipped reduce_rhs! / finish_aug_solve! / _kktmul! rows
+__global__ __launch_bounds__(TPB) void k25_fill_kernel(madqp_state s, double del_w, double del_c, double* a, double* b) {
+    const int64_t L = s.n > s.m ? s.n : s.m;
+    GRID_STRIDE(i, L) {
+        if (i < s.n) {
+            s.reg[i] = del_w;
+            a[i] = 1.0;
+            b[i] = 1.0;
+        }
+        if (i < s.m) s.du_diag[i] = del_c;
+    }
+}
+__global__ __launch_bounds__(TPB) void k25_bounds_kernel(madqp_state s, double* a, double* b) {
+    const int64_t L = s.nlb > s.nub ? s.nlb : s.nub;
+    GRID_STRIDE(i, L) {
+        if (i < s.nlb) {
+            const int64_t j = s.ind_lb[i];
+            const double ld = s.x[j] - s.xl[j];  // (X - Xl), src/kernels.jl:157
+            s.l_diag[i] = ld;
+            s.l_lower[i] = s.zl[j];
+            a[j] = ld;
+        }
+        if (i < s.nub) {
+            const int64_t j = s.ind_ub[i];
+            const double ud = s.xu[j] - s.x[j];  // (Xu - X), :158
+            s.u_diag[i] = ud;
+            s.u_lower[i] = s.zu[j];
+            b[j] = ud;
+        }
+    }
+}
+__global__ __launch_bounds__(TPB) void k25_final_kernel(madqp_state s, double del_w, double* a, const double* b) {
+    GRID_STRIDE(j, s.n) {
+        const double aj = a[j], bj = b[j];
+        s.pr_diag[j] = s.zl[j] * bj + s.zu[j] * aj + del_w * (aj * bj);
+        a[j] = sqrt(aj * bj);  // a becomes the scaling factor
+    }
+}
+__global__ __launch_bounds__(TPB) void k25_reduce_kernel(madqp_state s, double* w) {
+    const double* wzl = w + s.n + s.m;
+    const double* wzu = wzl + s.nlb;
+    // the two lists may name the same variable: two passes in one launch would race, so lb here, ub below
+    GRID_STRIDE(i, s.nlb) w[s.ind_lb[i]] += wzl[i] / s.l_diag[i];
+    (void)wzu;
+}
+__global__ __launch_bounds__(TPB) void k25_reduce_ub_kernel(madqp_state s, double* w) {
+    const double* wzu = w + s.n + s.m + s.nlb;
+    GRID_STRIDE(i, s.nub) w[s.ind_ub[i]] += wzu[i] / s.u_diag[i];
+}
+__global__ __launch_bounds__(TPB) void k25_finish_kernel(madqp_state s, double* w) {
+    const double* wx = w;
+    double* wzl = w + s.n + s.m;
+    double* wzu = wzl + s.nlb;
+    const int64_t L = s.nlb > s.nub ? s.nlb : s.nub;
+    GRID_STRIDE(i, L) {
+        if (i < s.nlb) wzl[i] = (wzl[i] - s.l_lower[i] * wx[s.ind_lb[i]]) / s.l_diag[i];
+        if (i < s.nub) wzu[i] = (s.u_lower[i] * wx[s.ind_ub[i]] - wzu[i]) / s.u_diag[i];
+    }
+}
+__global__ __launch_bounds__(TPB) void k25_kktmul_diag_kernel(madqp_state s, double* w, const double* v, double alpha) {
+    const int64_t L = s.n > s.m ? s.n : s.m;
+    GRID_STRIDE(i, L) {
+        if (i < s.n) w[i] += alpha * s.reg[i] * v[i];
+        if (i < s.m) w[s.n + i] += alpha * s.du_diag[i] * v[s.n + i];
+    }
+}
+__global__ __launch_bounds__(TPB) void k25_kktmul_lb_kernel(madqp_state s, double* w, const double* v, double alpha,
+                                                            double beta) {
+    double* wzl = w + s.n + s.m;
+    const double* vzl = v + s.n + s.m;
+    GRID_STRIDE(i, s.nlb) {
+        const int64_t j = s.ind_lb[i];
+        w[j] -= alpha * vzl[i];
+        wzl[i] = beta * wzl[i] + alpha * (v[j] * s.l_lower[i] + vzl[i] * s.l_diag[i]);
+    }
+}
+__global__ __launch_bounds__(TPB) void k25_kktmul_ub_kernel(madqp_state s, double* w, const double* v, double alpha,
+                                                            double beta) {
+    double* wzu = w + s.n + s.m + s.nlb;
+    const double* vzu = v + s.n + s.m + s.nlb;
+    GRID_STRIDE(i, s.nub) {
+        const int64_t j = s.ind_ub[i];
+        w[j] += alpha * vzu[i];
+        wzu[i] = beta * wzu[i] + alpha * (v[j] * s.u_lower[i] - vzu[i] * s.u_diag[i]);
+    }
+}
+__global__ __launch_bounds__(TPB) void k25_ones_kernel(int64_t n, double* a) {
+    GRID_STRIDE(i, n) a[i] = 1.0;
 }
 }  // namespace
 
@@ -157,6 +261,8 @@ extern "C" int32_t madqp_kkt_destroy(madqp_kkt* k) {
     if (k->dn) (void)hipFree(k->dn);
     if (k->tn) (void)hipFree(k->tn);
     if (k->b) (void)hipFree(k->b);
+    if (k->sfac) (void)hipFree(k->sfac);
+    if (k->sb) (void)hipFree(k->sb);
     delete k;
     return MADQP_OK;
 }
@@ -291,6 +397,27 @@ extern "C" int32_t madqp_kkt_create_augmented(madqp_ctx* ctx, int64_t nx, int64_
     return kkt_create_common(ctx, KKT_AUGMENTED, nx, m, ns, ind_ineq_host, H, ldh, A, lda, nullptr, 0, out);
 }
 
+// K2.5: the augmented system symmetrically scaled (MadNLP's ScaledSparseKKTSystem; see the header comment).
+extern "C" int32_t madqp_kkt_create_scaled_augmented(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
+                                                     const int64_t* ind_ineq_host, const double* H, int64_t ldh,
+                                                     const double* A, int64_t lda, madqp_kkt** out) {
+    int32_t r = madqp_kkt_create_augmented(ctx, nx, m, ns, ind_ineq_host, H, ldh, A, lda, out);
+    if (r) return r;
+    madqp_kkt* k = *out;
+    const int64_t n = nx + ns;
+    const size_t nb = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
+    hipError_t e = hipMalloc(&k->sfac, nb);
+    if (e == hipSuccess) e = hipMalloc(&k->sb, nb);
+    if (e != hipSuccess) {
+        madqp_kkt_destroy(k);
+        *out = nullptr;
+        return madqp_fail(ctx, MADQP_ERR_ALLOC, "madqp_kkt_create_scaled_augmented: %s", hipGetErrorString(e));
+    }
+    k->scaled = 1;
+    if (n) KLAUNCH(k25_ones_kernel, n, n, k->sfac);
+    return MADQP_OK;
+}
+
 extern "C" int32_t madqp_kkt_create_normal(madqp_ctx* ctx, int64_t nx, int64_t m, int64_t ns,
                                            const int64_t* ind_ineq_host, const double* At,
                                            int64_t ldat, madqp_kkt** out) {
@@ -338,14 +465,15 @@ static int32_t kkt_build_impl(madqp_kkt* k, const madqp_state* st, int64_t nrang
         const int64_t N = k->np + k->m;
         if (N == 0) return MADQP_OK;
         ProfScope ps(ctx, MADQP_PROF_SYRK);
-        if (k->m) KLAUNCH(aug_diag_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, k->theta);
+        const double* sf = k->scaled ? k->sfac : nullptr;
+        if (k->m) KLAUNCH(aug_diag_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, sf, k->theta);
         const unsigned tiles = (unsigned)((N + 63) / 64);
         hipLaunchKernelGGL(aug_fill_kernel, dim3(tiles, tiles), dim3(256), 0, ctx->stream, k->nx, k->np, k->m, k->H,
-                           k->ldh, k->hdiag, st->pr_diag, k->A, k->lda, k->theta, k->K, k->ldk);
+                           k->ldh, k->hdiag, st->pr_diag, k->A, k->lda, k->theta, sf, k->K, k->ldk);
         LAUNCH_CHECK(ctx);
         if (k->a_ptr && k->m) {
             hipLaunchKernelGGL(aug_scatter_kernel, dim3((unsigned)((k->m * 16 + 255) / 256)), dim3(256), 0, ctx->stream,
-                               k->m, k->np, k->a_ptr, k->a_col, k->a_val, k->K, k->ldk);
+                               k->m, k->np, k->a_ptr, k->a_col, k->a_val, sf, k->K, k->ldk);
             LAUNCH_CHECK(ctx);
         }
         return MADQP_OK;
@@ -363,6 +491,36 @@ static int32_t kkt_build_impl(madqp_kkt* k, const madqp_state* st, int64_t nrang
     }
     return madqp_syrk_assemble_ranges(ctx, k->nx, k->m, k->A, k->lda, k->theta, k->H, k->ldh, dvec,
                                       k->K, k->ldk, nranges, ranges);
+}
+
+// set_aug_diagonal_reg!(kkt, solver), dispatched on the KKT type as the reference does (src/kernels.jl:128 for every
+// AbstractKKTSystem, :149 for ScaledSparseKKTSystem)
+extern "C" int32_t madqp_kkt_set_aug_diagonal_reg(madqp_kkt* k, const madqp_state* st, double del_w, double del_c) {
+    int32_t r = check_kkt_state(k, st);
+    if (r) return r;
+    madqp_ctx* ctx = k->ctx;
+    if (!k->scaled) return madqp_set_aug_diagonal_reg(ctx, st, del_w, del_c);
+    ARG_TRY(ctx, st->x && st->xl && st->xu && st->zl && st->zu);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    if (std::max(st->n, st->m) > 0) KLAUNCH(k25_fill_kernel, std::max(st->n, st->m), *st, del_w, del_c, k->sfac, k->sb);
+    if (std::max(st->nlb, st->nub) > 0) KLAUNCH(k25_bounds_kernel, std::max(st->nlb, st->nub), *st, k->sfac, k->sb);
+    if (st->n) KLAUNCH(k25_final_kernel, st->n, *st, del_w, k->sfac, k->sb);
+    return MADQP_OK;
+}
+
+// MadNLP.initialize!(kkt) (src/KKT/normalkkt.jl:136-147): reg = pr_diag = 1, du_diag = 0, l_lower = u_lower = 0,
+// l_diag = u_diag = 1 -- and, for K2.5, scaling factor 1
+extern "C" int32_t madqp_kkt_initialize(madqp_kkt* k, const madqp_state* st) {
+    int32_t r = check_kkt_state(k, st);
+    if (r) return r;
+    madqp_ctx* ctx = k->ctx;
+    if ((r = madqp_fill(ctx, st->n, 1.0, st->reg)) || (r = madqp_fill(ctx, st->n, 1.0, st->pr_diag)) ||
+        (r = madqp_fill(ctx, st->m, 0.0, st->du_diag)) || (r = madqp_fill(ctx, st->nlb, 0.0, st->l_lower)) ||
+        (r = madqp_fill(ctx, st->nub, 0.0, st->u_lower)) || (r = madqp_fill(ctx, st->nlb, 1.0, st->l_diag)) ||
+        (r = madqp_fill(ctx, st->nub, 1.0, st->u_diag)))
+        return r;
+    if (k->scaled && st->n) KLAUNCH(k25_ones_kernel, st->n, st->n, k->sfac);
+    return MADQP_OK;
 }
 
 extern "C" int32_t madqp_kkt_build(madqp_kkt* k, const madqp_state* st) {
@@ -399,7 +557,13 @@ extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* 
     ARG_TRY(ctx, w != nullptr);
     double* wx = w;
     double* wy = w + st->n;
-    if ((r = madqp_reduce_rhs(ctx, st, w))) return r;
+    if (k->scaled) {  // r1 = p_x + p_zl / l_diag + p_zu / u_diag (signs of src/kernels.jl:157-158)
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        if (st->nlb) KLAUNCH(k25_reduce_kernel, st->nlb, *st, w);
+        if (st->nub) KLAUNCH(k25_reduce_ub_kernel, st->nub, *st, w);
+    } else if ((r = madqp_reduce_rhs(ctx, st, w))) {
+        return r;
+    }
     if (k->mode == KKT_NORMAL) {  // src/KKT/normalkkt.jl:185-201
         {
             ProfScope ps(ctx, MADQP_PROF_VEC);
@@ -421,14 +585,20 @@ extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* 
     }
     if (k->mode == KKT_AUGMENTED) {
         const int64_t N = k->np + k->m;
+        const double* sf = k->scaled ? k->sfac : nullptr;
         if (N) {
             ProfScope ps(ctx, MADQP_PROF_VEC);
-            KLAUNCH(aug_rhs_kernel, N, k->nx, k->np, k->m, k->d_slot, st->pr_diag, wx, wy, k->b);
+            KLAUNCH(aug_rhs_kernel, N, k->nx, k->np, k->m, k->d_slot, st->pr_diag, sf, wx, wy, k->b);
         }
         if ((r = madqp_chol_solve(k->chol, k->b))) return r;
         if (k->nx + k->m) {
             ProfScope ps(ctx, MADQP_PROF_VEC);
-            KLAUNCH(aug_back_kernel, k->nx + k->m, k->nx, k->np, k->m, k->d_slot, st->pr_diag, k->b, wx, wy);
+            KLAUNCH(aug_back_kernel, k->nx + k->m, k->nx, k->np, k->m, k->d_slot, st->pr_diag, sf, k->b, wx, wy);
+        }
+        if (k->scaled) {
+            ProfScope ps(ctx, MADQP_PROF_VEC);
+            if (std::max(st->nlb, st->nub) > 0) KLAUNCH(k25_finish_kernel, std::max(st->nlb, st->nub), *st, w);
+            return MADQP_OK;
         }
         return madqp_finish_aug_solve(ctx, st, w);
     }
@@ -489,6 +659,13 @@ extern "C" int32_t madqp_kkt_mul(madqp_kkt* k, const madqp_state* st, double* w,
         if ((r = apply_A(k, 1.0, v, 0.0, k->u))) return r;
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(mul_rows_kernel, k->m, k->m, k->d_slot, k->u, v + nx, w + n, alpha, beta);
+    }
+    if (k->scaled) {  // mul!(w, ::ScaledSparseKKTSystem, v): zl dx + l_diag dzl, zu dx - u_diag dzu
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        if (std::max(st->n, st->m) > 0) KLAUNCH(k25_kktmul_diag_kernel, std::max(st->n, st->m), *st, w, v, alpha);
+        if (st->nlb) KLAUNCH(k25_kktmul_lb_kernel, st->nlb, *st, w, v, alpha, beta);
+        if (st->nub) KLAUNCH(k25_kktmul_ub_kernel, st->nub, *st, w, v, alpha, beta);
+        return MADQP_OK;
     }
     return madqp_kktmul(ctx, st, w, v, alpha, beta);
 }

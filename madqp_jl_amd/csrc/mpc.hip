@@ -57,7 +57,7 @@ void update_regularization(madqp_mpc* s) {
 // src/linear_solver.jl:6-17
 int32_t factorize_regularized_system(madqp_mpc* s) {
     for (int trial = 0; trial < 3; ++trial) {
-        TRY(madqp_set_aug_diagonal_reg(s->ctx, &s->st, s->del_w, s->del_c));
+        TRY(madqp_kkt_set_aug_diagonal_reg(s->kkt, &s->st, s->del_w, s->del_c));  // dispatched on the KKT type
         TRY(madqp_kkt_build(s->kkt, &s->st));
         TRY(madqp_kkt_factorize(s->kkt, &s->last_info));
         s->n_factorizations += 1;

@@ -107,6 +107,11 @@ class HIPCondensedKKTSystem:
                      (st.u_lower, 0.0), (st.l_diag, 1.0), (st.u_diag, 1.0)):
             be.fill(v, t)
 
+    def set_aug_diagonal_reg(self, del_w, del_c):
+        """``set_aug_diagonal_reg!(kkt, solver)`` -- dispatched on the KKT type (src/kernels.jl:128-146; the
+        ``ScaledSparseKKTSystem`` method of :149-165 is :class:`HIPScaledAugmentedKKTSystem`)."""
+        self.be.set_aug_diagonal_reg(self.st, del_w, del_c)
+
     def jtprod(self, out, y):  # MadNLP.jtprod!, :162-164
         self.be.kkt_jtprod(self._h, out, y)
 
@@ -187,6 +192,34 @@ class HIPAugmentedKKTSystem(HIPCondensedKKTSystem):
 
     def is_inertia_correct(self, num_pos, num_zero, num_neg):  # src/KKT/normalkkt.jl:132-134, K2 inertia
         return num_zero == 0 and num_neg == self.m
+
+
+class HIPScaledAugmentedKKTSystem(HIPAugmentedKKTSystem):
+    """K2.5: MadNLP's ``ScaledSparseKKTSystem`` (``kkt_system=MadNLP.ScaledSparseKKTSystem`` in test/runtests.jl:95-115)
+    on the dense quasi-definite path: the augmented matrix scaled symmetrically by ``sqrt((x - xl)(xu - x))`` per variable
+    (scripts/cuda_wrapper.jl:90-116), ``l_diag = x - xl``, ``u_diag = xu - x`` positive (src/kernels.jl:149-165).  Same
+    iterates as the K2 form; every entry of the matrix stays bounded as the iterates converge."""
+
+    def __init__(self, backend, st: State, nx, ind_ineq, H, A):
+        self.be, self.st = backend, st
+        self.nx, self.m = int(nx), st.m
+        self.ind_ineq = [int(i) for i in ind_ineq]
+        self.ns = len(self.ind_ineq)
+        assert st.n == self.nx + self.ns
+        self.H, self.A = H, A
+        if H is not None:
+            assert H.is_contiguous() and tuple(H.shape) == (nx, nx)
+        assert A.is_contiguous() and tuple(A.shape) == (self.m, self.nx)
+        self._h = backend.kkt_create_scaled_augmented(self.nx, self.m, self.ind_ineq, H, max(self.nx, 1), A,
+                                                      max(self.nx, 1))
+        self.linear_solver = HIPQuasiDefiniteSolver(backend, self._h, self.nx, self.m)
+        self.n_factorizations = 0
+
+    def initialize(self):  # MadNLP.initialize!(kkt): also the scaling factor (library owned) = 1
+        self.be.kkt_initialize(self._h, self.st)
+
+    def set_aug_diagonal_reg(self, del_w, del_c):  # src/kernels.jl:149-165
+        self.be.kkt_set_aug_diagonal_reg(self._h, self.st, del_w, del_c)
 
 
 class _SparseMixin:

@@ -18,8 +18,8 @@ import numpy as np
 import torch
 
 from ._lib import CMpcInfo, CMpcOptions
-from .kkt import (HIPAugmentedKKTSystem, HIPCondensedKKTSystem, HIPNormalKKTSystem, HIPSparseAugmentedKKTSystem,
-                  HIPSparseCondensedKKTSystem, HIPSparseNormalKKTSystem)
+from .kkt import (HIPAugmentedKKTSystem, HIPCondensedKKTSystem, HIPNormalKKTSystem, HIPScaledAugmentedKKTSystem,
+                  HIPSparseAugmentedKKTSystem, HIPSparseCondensedKKTSystem, HIPSparseNormalKKTSystem)
 from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, FixedRegularization,
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
 from .qp import DeviceCSR, DeviceQP
@@ -93,7 +93,7 @@ class MPCSolver:
         host = lambda t: t.detach().cpu().numpy()
         # src/utils.jl:81: RelaxBound for condensed KKT systems, MakeParameter otherwise
         fvt = self.opt.fixed_variable_treatment or (
-            "relax_bound" if self.opt.kkt_system in ("condensed", "augmented") else "make_parameter")
+            "relax_bound" if self.opt.kkt_system in ("condensed", "augmented", "scaled_augmented") else "make_parameter")
         if fvt not in ("relax_bound", "make_parameter", "error"):
             raise ValueError(f"unknown fixed_variable_treatment {fvt!r}")
         self.full_qp, self._fixed = qp, None
@@ -111,13 +111,15 @@ class MPCSolver:
         self.st = backend.new_state(self.n, self.m, ic["ind_lb"], ic["ind_ub"])
         self.nlb, self.nub = self.st.nlb, self.st.nub
         reg = self.opt.regularization
-        if self.opt.kkt_system not in ("condensed", "normal", "augmented"):
+        if self.opt.kkt_system not in ("condensed", "normal", "augmented", "scaled_augmented"):
             raise ValueError(f"unknown kkt_system {self.opt.kkt_system!r}")
         diag_h = qp.H is not None and qp.H.dim() == 1  # H = diag(vector): sparse front end only
+        if self.opt.kkt_system == "scaled_augmented" and (diag_h or isinstance(qp.A, DeviceCSR)):
+            raise ValueError("the scaled augmented (K2.5) system takes a dense Jacobian and a dense (or no) Hessian")
         if diag_h and not isinstance(qp.A, DeviceCSR) and self.opt.kkt_system != "augmented":
             raise ValueError("a diagonal Hessian (1-D tensor) needs the sparse front end (A as DeviceCSR) "
                              "or kkt_system='augmented'")
-        if self.opt.kkt_system == "augmented" and self.opt.distributed:
+        if self.opt.kkt_system in ("augmented", "scaled_augmented") and self.opt.distributed:
             raise ValueError("the augmented KKT system is factorised on one GPU")
         if self.opt.kkt_system == "normal" and qp.H is not None and not diag_h:
             raise ValueError("The KKT system NormalKKTSystem supports only linear programs.")
@@ -198,7 +200,7 @@ class MPCSolver:
     # ---- src/linear_solver.jl ----
     def factorize_regularized_system(self):  # :6-17
         for _ in range(3):
-            self.be.set_aug_diagonal_reg(self.st, self.del_w, self.del_c)
+            self.kkt.set_aug_diagonal_reg(self.del_w, self.del_c)
             self.kkt.factorize_wrapper()
             if self.kkt.linear_solver.is_factorized():
                 break
@@ -334,6 +336,8 @@ class MPCSolver:
             return cls(be, st, nx, self.ind_ineq, self.H, self.A)
         if opt.kkt_system == "augmented":
             return HIPAugmentedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)
+        if opt.kkt_system == "scaled_augmented":
+            return HIPScaledAugmentedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)
         if opt.kkt_system == "normal":
             self.At = self.A.t().contiguous()  # (nx, m): the layout the normal-equations GEMM consumes
             return normal_cls(be, st, nx, self.ind_ineq, self.H, self.At, **extra)

@@ -13,6 +13,8 @@ tests of the reference (``test/runtests.jl:102-115,165-180``):
 
 ``K2``         augmented system ``[H+S, A'; A, dc I]`` (MadNLP's default
                ``SparseKKTSystem``; symmetric indefinite solve)
+``K2.5``       the same system symmetrically scaled (``ScaledSparseKKTSystem``,
+               src/kernels.jl:149-165, test/runtests.jl:95-115)
 ``normal``     ``A S^-1 A'`` -- ``src/KKT/normalkkt.jl`` verbatim (LP only)
 ``condensed``  ``H + S_x + A_x' Th A_x`` -- the generalisation the HIP path
                implements; Cholesky
@@ -263,6 +265,82 @@ class K2KKT(DenseKKT):
         return w
 
 
+class K25KKT(DenseKKT):
+    """K2.5: MadNLP's ``ScaledSparseKKTSystem`` as MadIPM drives it (src/kernels.jl:149-165, the scaling kernel of
+    scripts/cuda_wrapper.jl:90-116; equality of K2.5 and K2 results: test/runtests.jl:95-115).
+
+    *MadNLP-recall* for ``_set_aug_diagonal!`` / ``solve!`` / ``mul!`` of that type, restated from the algebra they
+    implement.  Sign convention of src/kernels.jl:157-158: ``l_diag = x - xl > 0``, ``u_diag = xu - x > 0``.  With
+    ``a_j = l_diag`` (1 without a lower bound), ``b_j = u_diag`` (1 without an upper bound):
+
+        scaling_j = sqrt(a_j b_j),      pr_diag_j = zl_j b_j + zu_j a_j + del_w a_j b_j   ( = scaling^2 (del_w + Sigma) )
+
+    and the matrix that is factorised is the symmetric scaling of the K2 matrix, entry by entry as the COO kernel does
+    it (:96-110): pr_diag as it stands, Hessian entries times scaling_i scaling_j, Jacobian entries times scaling_j,
+    du_diag as it stands.  Its entries stay bounded as the iterates converge (Sigma itself blows up on active bounds).
+    Unreduced system (the rows of mul!):  zl dx_lr + l_diag dzl = p_zl,   zu dx_ur - u_diag dzu = p_zu.
+    """
+
+    def __init__(self, solver):
+        super().__init__(solver)
+        self.scaling_factor = np.ones(solver.n)
+
+    def initialize(self):
+        super().initialize()
+        self.scaling_factor[:] = 1.0
+
+    def set_aug_diagonal(self, zl, zu, del_w):  # MadNLP._set_aug_diagonal!(kkt) (src/kernels.jl:163)
+        s = self.s
+        a, b = np.ones(s.n), np.ones(s.n)
+        a[s.ind_lb] = self.l_diag
+        b[s.ind_ub] = self.u_diag
+        self.scaling_factor[:] = np.sqrt(a * b)
+        self.pr_diag[:] = zl * b + zu * a + del_w * (a * b)
+
+    def build_and_factorize(self):
+        s = self.s
+        n, m, sf = s.n, s.m, self.scaling_factor
+        K = np.zeros((n + m, n + m))
+        K[: s.nx, : s.nx] = s.H * sf[: s.nx, None] * sf[None, : s.nx]  # Hessian block: V * scaling[i] * scaling[j]
+        K[np.arange(n), np.arange(n)] += self.pr_diag  # primal diagonal: copied
+        K[n:, :n] = s.A_full * sf[None, :]  # Jacobian block: V * scaling[j]
+        K[:n, n:] = K[n:, :n].T
+        K[np.arange(n, n + m), np.arange(n, n + m)] = self.du_diag  # dual regularization: copied
+        self.K = K
+        self.n_factorizations += 1
+        try:
+            self.lu = sla.lu_factor(K)
+            self.factorized = bool(np.all(np.isfinite(self.lu[0])))
+        except Exception:
+            self.factorized = False
+
+    def solve(self, w: KKTVec):
+        s, sf = self.s, self.scaling_factor
+        # reduce: r1 = p_x + p_zl / l_diag + p_zu / u_diag, then the symmetric scaling of the primal block
+        w.xp[w.ind_lb] += w.zl / self.l_diag
+        w.xp[w.ind_ub] += w.zu / self.u_diag
+        rhs = np.concatenate([sf * w.xp, w.y])
+        sol = sla.lu_solve(self.lu, rhs)
+        w.xp[:] = sf * sol[: s.n]
+        w.y[:] = sol[s.n :]
+        w.zl[:] = (w.zl - self.l_lower * w.xp[w.ind_lb]) / self.l_diag
+        w.zu[:] = (self.u_lower * w.xp[w.ind_ub] - w.zu) / self.u_diag
+        return w
+
+    def mul(self, w: KKTVec, v: KKTVec, alpha=1.0, beta=0.0):
+        s = self.s
+        w.xp[:] = alpha * (s.A_full.T @ v.y) + beta * w.xp
+        w.xp[: s.nx] += alpha * (s.H @ v.xp[: s.nx])
+        w.y[:] = alpha * (s.A_full @ v.xp) + beta * w.y
+        w.xp[:] += alpha * self.reg * v.xp
+        w.y[:] += alpha * self.du_diag * v.y
+        w.xp[w.ind_lb] -= alpha * v.zl
+        w.xp[w.ind_ub] += alpha * v.zu
+        w.zl[:] = beta * w.zl + alpha * (v.xp[v.ind_lb] * self.l_lower + v.zl * self.l_diag)
+        w.zu[:] = beta * w.zu + alpha * (v.xp[v.ind_ub] * self.u_lower - v.zu * self.u_diag)
+        return w
+
+
 class NormalKKT(DenseKKT):
     """src/KKT/normalkkt.jl verbatim, dense storage; LP only (:45-48)."""
 
@@ -348,7 +426,7 @@ class CondensedKKT(DenseKKT):
         return w
 
 
-_KKT = {"K2": K2KKT, "normal": NormalKKT, "condensed": CondensedKKT}
+_KKT = {"K2": K2KKT, "K2.5": K25KKT, "normal": NormalKKT, "condensed": CondensedKKT}
 
 
 # --------------------------------------------------------------------------
@@ -447,10 +525,17 @@ class MPCSolver:
         du = np.where(v < tmin, tmin - v, np.where(v > tmax, tmax - v, 0.0))
         self.correction_ub[:] = self.correction_ub + du
 
-    def set_aug_diagonal_reg(self):  # kernels.jl:128-146
+    def set_aug_diagonal_reg(self):  # kernels.jl:128-146; ScaledSparseKKTSystem: :149-165
         k = self.kkt
         k.reg[:] = self.del_w
         k.du_diag[:] = self.del_c
+        if isinstance(k, K25KKT):
+            k.l_diag[:] = self.x_lr - self.xl_r  # :157 (X - Xl)
+            k.u_diag[:] = self.xu_r - self.x_ur  # :158 (Xu - X)
+            k.l_lower[:] = self.zl_r
+            k.u_lower[:] = self.zu_r
+            k.set_aug_diagonal(self.zl, self.zu, self.del_w)  # :163
+            return
         k.l_diag[:] = self.xl_r - self.x_lr
         k.u_diag[:] = self.x_ur - self.xu_r
         k.l_lower[:] = self.zl_r

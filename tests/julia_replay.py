@@ -93,9 +93,9 @@ class ReplayKKTSystem:
         if form == "condensed":
             ccall(be, "madqp_kkt_create", be.ctx, self.nx, self.m, self.ns, ineq0, ptr(self.H), ldh, ptr(self.At),
                   self.lda, C.byref(h))
-        elif form == "augmented":
-            ccall(be, "madqp_kkt_create_augmented", be.ctx, self.nx, self.m, self.ns, ineq0, ptr(self.H), ldh,
-                  ptr(self.At), self.lda, C.byref(h))
+        elif form in ("augmented", "scaled_augmented"):
+            ccall(be, "madqp_kkt_create_augmented" if form == "augmented" else "madqp_kkt_create_scaled_augmented",
+                  be.ctx, self.nx, self.m, self.ns, ineq0, ptr(self.H), ldh, ptr(self.At), self.lda, C.byref(h))
         else:
             ccall(be, "madqp_kkt_create_normal", be.ctx, self.nx, self.m, self.ns, ineq0, ptr(self.At), self.lda,
                   C.byref(h))
@@ -138,10 +138,11 @@ class ReplayKKTSystem:
     def get_hessian(self):
         return self.hess
 
-    def initialize(self):  # MadNLP.initialize!(kkt): plain fill! broadcasts
-        for t, v in ((self.reg, 1.0), (self.pr_diag, 1.0), (self.du_diag, 0.0), (self.l_lower, 0.0),
-                     (self.u_lower, 0.0), (self.l_diag, 1.0), (self.u_diag, 1.0)):
-            t.fill_(v)
+    def initialize(self):  # MadNLP.initialize!(kkt)
+        ccall(self.be, "madqp_kkt_initialize", self.handle, C.byref(self.cstate))
+
+    def set_aug_diagonal_reg(self, del_w, del_c):  # MadIPM.set_aug_diagonal_reg!(kkt, solver): state(solver)
+        ccall(self.be, "madqp_kkt_set_aug_diagonal_reg", self.handle, C.byref(self.solver_state.cstruct), del_w, del_c)
 
     def compress_jacobian(self):
         ccall(self.be, "madqp_coo_map_apply", self.jac_map, ptr(self.jac), ptr(self.At), self.lda)
@@ -179,6 +180,7 @@ class ReplayState(M.State):
             setattr(self, k, getattr(kkt, k))
         self.ind_lb, self.ind_ub = kkt.ind_lb0, kkt.ind_ub0
         self._c = None  # state(solver) of the glue is built after the KKT system exists
+        kkt.solver_state = self
 
 
 class ReplayBackend(M.HipBackend):
@@ -194,7 +196,7 @@ class ReplayBackend(M.HipBackend):
             return getattr(M.HipBackend, name)(self, *a, **k)
         return call
 
-    for _n in ("set_aug_diagonal_reg", "set_initial_primal_rhs", "set_initial_dual_rhs", "set_predictive_rhs",
+    for _n in ("set_initial_primal_rhs", "set_initial_dual_rhs", "set_predictive_rhs",
                "set_correction_rhs", "get_correction", "set_extra_correction", "get_complementarity_measure",
                "get_affine_complementarity_measure", "get_alpha_max"):
         locals()[_n] = _bound(_n)

@@ -229,3 +229,90 @@ def test_augmented_golden_traces(hip, name, driver):
     compare_traces(r["trace"], g["trace"], name)
     assert close(r["objective"], g["objective"], 1e-9)
     assert np.max(np.abs(r["solution"] - np.array(g["solution"]))) <= 1e-7
+
+
+# ---- K2.5: MadNLP's ScaledSparseKKTSystem (src/kernels.jl:149-165, scripts/cuda_wrapper.jl:90-116) ----
+def solve_k25(qp, be, **opts):
+    s = M.MPCSolver(to_device(qp, be), be, kkt_system="scaled_augmented", **opts)
+    r = s.solve()
+    s.close()
+    return r
+
+
+K25_CASES = {"dummy_10_5": lambda: Q.dummy_qp(10, 5), "hs21": Q.hs21, "simple_lp": Q.simple_lp,
+             "dummy_20_15_eq": lambda: Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)),
+             "random_130_70": lambda: Q.random_qp(5, 130, 70),  # free / one-sided / boxed variables, ranged rows
+             "synthetic_300_120": lambda: Q.synthetic_qp(20250914, 300, 120)}
+
+
+@DRIVERS
+@pytest.mark.parametrize("name", list(K25_CASES))
+def test_k25_vs_oracle(hip, name, driver):
+    """The device K2.5 path follows the oracle's K2.5 path trace for trace (reference default options)."""
+    qp = K25_CASES[name]()
+    r = solve_k25(qp, hip, driver=driver, max_ncorr=2 if name == "random_130_70" else 0)
+    ref = mpc.solve(qp, kkt_system="K2.5", max_ncorr=2 if name == "random_130_70" else 0)
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
+    compare_traces(r["trace"], ref["trace"], f"K2.5 {name}")
+    assert close(r["objective"], ref["objective"], 1e-9)
+    assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+    assert np.max(np.abs(r["multipliers"] - ref["multipliers"])) <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["dummy_10_5", "dummy_20_15_eq", "random_130_70"])
+def test_k25_equals_k2(hip, name):
+    """test/runtests.jl:95-115 on the device: K2.5 gives the same iteration count, objective, solution, constraints and
+    multipliers as K2 (atol 1e-6) -- both through the HIP path (the reference compares two of its own KKT systems)."""
+    qp = K25_CASES[name]()
+    k2, k25 = solve_aug(qp, hip), solve_k25(qp, hip)
+    assert k25["status"] == k2["status"] == M.SOLVE_SUCCEEDED
+    assert k25["iter"] == k2["iter"]
+    assert abs(k25["objective"] - k2["objective"]) <= 1e-6
+    for key in ("solution", "constraints", "multipliers"):
+        assert np.max(np.abs(k25[key] - k2[key])) <= 1e-6, key
+
+
+def test_k25_conformance_and_bounded_entries(hip):
+    """MadNLPTests.test_kkt_system-style check at a LATE iterate (mu ~ 1e-9: Sigma spans 16 orders of magnitude):
+    K * solve(b) == b through the unreduced mul! of the scaled system, the solution equals the oracle's, and the
+    entries of the scaled matrix stay bounded where those of the K2 matrix blow up."""
+    rng = np.random.default_rng(9)
+    qp = Q.dummy_qp(40, 18, equality_cons=(2, 9))
+    ref = mpc.MPCSolver(qp, kkt_system="K2.5")
+    ref.initialize()
+    while ref.iteration_head() is None and ref.mu > 1e-9:
+        ref.iteration_body()
+    s = M.MPCSolver(to_device(qp, hip), hip, kkt_system="scaled_augmented")
+    s.initialize()
+    st = s.st
+    for name in ("x", "xl", "xu", "zl", "zu", "y"):  # put the device state at the oracle's late iterate
+        getattr(st, name).copy_(torch.as_tensor(getattr(ref, name), device=hip.device))
+    s.del_w, s.del_c = ref.del_w, ref.del_c = 1e-8, 0.0
+    ref.set_aug_diagonal_reg()
+    s.kkt.set_aug_diagonal_reg(s.del_w, s.del_c)
+    for f in ("pr_diag", "l_diag", "u_diag", "l_lower", "u_lower"):
+        np.testing.assert_allclose(getattr(st, f).cpu().numpy(), getattr(ref.kkt, f), rtol=1e-13, atol=0)
+    assert np.all(ref.kkt.l_diag > 0) and np.all(ref.kkt.u_diag > 0)  # signs of src/kernels.jl:157-158
+    s.kkt.factorize_wrapper()
+    ref.kkt.build_and_factorize()
+    assert s.kkt.linear_solver.is_factorized()
+    sigma_k2 = ref.del_w + ref.zl / np.where(np.isfinite(ref.xl), ref.x - ref.xl, np.inf) \
+        + ref.zu / np.where(np.isfinite(ref.xu), ref.xu - ref.x, np.inf)
+    assert sigma_k2.max() > 1e6 and ref.kkt.pr_diag.max() < 1e2 * max(1.0, np.abs(qp.H).max())
+    b = rng.standard_normal(st.ntot)
+    st.p.copy_(torch.as_tensor(b))
+    hip.copy(st.p, st.d)
+    s.kkt.solve(st.d)
+    hip.fill(0.0, st.w1)
+    s.kkt.mul(st.w1, st.d, 1.0, 0.0)
+    w = mpc.KKTVec(ref.n, ref.m, ref.nlb, ref.nub, ref.ind_lb, ref.ind_ub)
+    w.values[:] = b
+    ref.kkt.solve(w)
+    scale = max(1.0, np.max(np.abs(w.values)))
+    assert np.max(np.abs(st.d.cpu().numpy() - w.values)) <= 1e-8 * scale
+    ow = mpc.KKTVec(ref.n, ref.m, ref.nlb, ref.nub, ref.ind_lb, ref.ind_ub)
+    ref.kkt.mul(ow, w, 1.0, 0.0)
+    res_oracle = np.max(np.abs(ow.values - b)) / max(1.0, np.max(np.abs(b)))
+    res = np.max(np.abs(st.w1.cpu().numpy() - b)) / max(1.0, np.max(np.abs(b)))
+    assert res <= max(10.0 * res_oracle, 1e-10), (res, res_oracle)
+    s.close()

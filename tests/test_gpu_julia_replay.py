@@ -112,6 +112,8 @@ CASES = [
     # equality rows exactly -- the condensed form's Theta = 1e8 puts a 2e-7 noise floor under the traces
     # (test_gpu_solver.py::test_kkt_system_conformance), too coarse for the 1e-9 trace comparison used here
     ("random_130_70/augmented", lambda: Q.random_qp(5, 130, 70), "augmented", "K2", (1e-8, 0.0), 0),
+    ("dummy_10_5/scaled_augmented", lambda: Q.dummy_qp(10, 5), "scaled_augmented", "K2.5", (1e-8, 0.0), 0),
+    ("random_130_70/scaled_augmented/gondzio", lambda: Q.random_qp(5, 130, 70), "scaled_augmented", "K2.5", (1e-8, 0.0), 2),
     ("synthetic_lp_30_12/normal", lambda: Q.synthetic_qp(20250615, 30, 12, "lp"), "normal", "normal", (1e-8, 0.0), 0),
 ]
 
@@ -137,6 +139,7 @@ def test_every_symbol_the_glue_binds_was_replayed(rbe):
     Gondzio corrections, so that set_extra_correction! runs)."""
     for form, make, reg in (("condensed", lambda: Q.dummy_qp(10, 5), (1e-8, -1e-8)),
                             ("augmented", lambda: Q.dummy_qp(10, 5), (1e-8, 0.0)),
+                            ("scaled_augmented", lambda: Q.dummy_qp(10, 5), (1e-8, 0.0)),
                             ("normal", lambda: Q.simple_lp(), (1e-8, 0.0))):
         s = JR.ReplayMPCSolver(to_device(make(), rbe), rbe, kkt_system=form,
                                regularization=M.FixedRegularization(*reg), max_ncorr=2)

@@ -341,11 +341,16 @@ def test_batch_of_independent_qps(hip):
 
 
 def test_full_size_c_main_properties(hip):
+    """... and, at this size only, the ORACLE itself: tests/golden/cmain_first_iteration.json holds the trace of
+    oracle/mpc.py run at n_x = 50 000, m = 20 000 on a GPU box's host (`bench.py --cpu-full`, 88 s per iteration): the
+    device iterate before and after the first iteration must match it to the stated per-iteration tolerance."""
     torch.cuda.empty_cache()
-    full_size_properties(hip, 50000, 20000, 20250614 + 1)
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cmain_first_iteration.json")))
+    assert (golden["nx"], golden["m"], golden["seed"]) == (50000, 20000, 20250614 + 1)
+    full_size_properties(hip, 50000, 20000, 20250614 + 1, golden=golden)
 
 
-def full_size_properties(hip, nx, m, seed):
+def full_size_properties(hip, nx, m, seed, golden=None):
     """BASELINE metric size (n_x = 50 000, m = 20 000; also configs[4], tests/test_gpu_configs.py): far beyond the oracle, so size-independent
     properties through the same C ABI: (a) the on-device generator reproduces randomly chosen tiles of
     A, H and q bit for bit; (b) the assembled condensed K equals H + Sigma + A' Theta A on sampled
@@ -371,7 +376,8 @@ def full_size_properties(hip, nx, m, seed):
     np.testing.assert_array_equal(dq.q[:1000].cpu().numpy(), Q.gen_q(seed, nx)[:1000])
 
     s = M.MPCSolver(dq, hip, max_iter=300, step_rule=M.AdaptiveStep(0.995),
-                    regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12)
+                    regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12,
+                    max_ncorr=golden["max_ncorr"] if golden else 0)
     s.initialize()
     assert s.last_residual_ratio < 1e-8
     st = s.st
@@ -401,6 +407,10 @@ def full_size_properties(hip, nx, m, seed):
         assert s.last_residual_ratio < 1e-7, s.last_residual_ratio
         assert s.iteration_head() is None
     assert s.inf_pr < pr0 and 0 < s.alpha_p <= 1 and 0 < s.alpha_d <= 1
+    if golden:  # the oracle's own trace at this size (mu >= 1e-4: tolerance 1e-9)
+        for t, g in zip(s.trace, golden["trace"]):
+            for key in ("inf_pr", "inf_du", "inf_compl", "mu", "alpha_p", "alpha_d"):
+                assert close(t[key], g[key], 1e-9), (t["k"], key, t[key], g[key])
     s.close()
     del s, dq
     torch.cuda.empty_cache()

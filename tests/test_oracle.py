@@ -231,3 +231,16 @@ def test_fixed_variables_relax_bound_equals_elimination():
         assert r["status"] == ref["status"] == mpc.SOLVE_SUCCEEDED
         assert abs(r["objective"] - ref["objective"]) < 1e-6 and np.allclose(r["solution"][fixed], vals, atol=1e-7)
         assert np.max(np.abs(r["solution"][keep] - ref["solution"])) < 1e-5
+
+
+@pytest.mark.parametrize("make", [lambda: Q.dummy_qp(10, 5), lambda: Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)),
+                                  lambda: Q.random_qp(5, 130, 70), lambda: Q.simple_lp()])
+def test_k25_equals_k2(make):
+    """test/runtests.jl:95-115: ScaledSparseKKTSystem (K2.5) gives the same iteration count, objective, solution,
+    constraints and multipliers as the default K2 system (atol 1e-6)."""
+    qp = make()
+    k2, k25 = mpc.solve(qp, kkt_system="K2"), mpc.solve(qp, kkt_system="K2.5")
+    assert k2["status"] == k25["status"] == mpc.SOLVE_SUCCEEDED and k2["iter"] == k25["iter"]
+    assert abs(k2["objective"] - k25["objective"]) <= 1e-6
+    for key in ("solution", "constraints", "multipliers"):
+        assert np.max(np.abs(k2[key] - k25[key])) <= 1e-6
