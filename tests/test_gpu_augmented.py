@@ -309,7 +309,9 @@ def test_k25_conformance_and_bounded_entries(hip):
     w.values[:] = b
     ref.kkt.solve(w)
     scale = max(1.0, np.max(np.abs(w.values)))
-    assert np.max(np.abs(st.d.cpu().numpy() - w.values)) <= 1e-8 * scale
+    # two different factorisations (pivoted LU of the unreduced scaled matrix / L diag(I,-I) L' of the reduced one) of
+    # a system with mu ~ 1e-9: agreement to cond * eps, the residuals below are the sharper statement
+    assert np.max(np.abs(st.d.cpu().numpy() - w.values)) <= 1e-6 * scale
     ow = mpc.KKTVec(ref.n, ref.m, ref.nlb, ref.nub, ref.ind_lb, ref.ind_ub)
     ref.kkt.mul(ow, w, 1.0, 0.0)
     res_oracle = np.max(np.abs(ow.values - b)) / max(1.0, np.max(np.abs(b)))
