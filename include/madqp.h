@@ -340,6 +340,44 @@ int32_t madqp_chol_panel_unpack(madqp_chol* s, int64_t j0, int64_t w, const doub
 /* info as madqp_chol_factor (first failing column over all ranks: it travels in the packed image) */
 int32_t madqp_chol_factor_end(madqp_chol* s, int32_t* info_host);
 
+/* ----------------------------------------- one dense KKT matrix on a P x Q grid of GPUs */
+/* 2-D block-cyclic distributed Cholesky + triangular solves, one process per GPU: the AbstractLinearSolver contract
+ * (factorize! / solve!, src/KKT/normalkkt.jl:99-101,196; src/linear_solver.jl:10) for a matrix that no longer fits --
+ * or is no longer worth factorising on -- one GPU.  The reference has no counterpart (single process).
+ *   grid     rank = p*Q + q, 0 <= p < P, 0 <= q < Q, P*Q = world (8 GPUs: 2 x 4);
+ *   layout   tile (I, J) of the lower triangle (nb x nb, nb a multiple of 128) lives on rank (I mod P, J mod Q) at
+ *            position (I div P, J div Q) of that rank's column-major local matrix (madqp_dist_matrix): the caller (or
+ *            madqp_dkkt_*) fills the local tiles with K, factor overwrites them with L;
+ *   factor   right-looking over tile columns with look-ahead 1: diagonal tile -> broadcast down its process column ->
+ *            panel solves -> the panel is broadcast along process rows and, transposed, down process columns -> one
+ *            MFMA GEMM per rank and step; info as LAPACK dpotrf, identical on all ranks;
+ *   solve    rhs: n doubles, replicated on every rank, overwritten with the solution (forward and backward sweeps
+ *            over the tiles: one reduction to the diagonal owner and one broadcast per tile).
+ * Collectives: RCCL over xGMI -- rank 0 draws an id with madqp_dist_unique_id and the caller ships those 128 bytes to
+ * every rank (any channel), create builds the world / row / column communicators; the calls run on internal streams
+ * of the context, ordered after what the context's stream held at the call and finished (joined) before it goes on.
+ * For rehearsals with several ranks on one GPU (RCCL refuses that) the caller passes host-staged collectives instead
+ * (madqp_comm_ops; tests use torch.distributed gloo): group 0 = world, 1 = my process row, 2 = my process column;
+ * root = rank inside the group (q in a row group, p in a column group). */
+typedef struct madqp_dist madqp_dist;
+typedef struct madqp_comm_ops {
+    void* user;
+    int32_t (*bcast)(void* user, void* host_buf, int64_t bytes, int32_t root, int32_t group);
+    int32_t (*reduce_sum)(void* user, double* host_buf, int64_t count, int32_t root, int32_t group);
+    int32_t (*allreduce_sum)(void* user, double* host_buf, int64_t count, int32_t group);
+} madqp_comm_ops;
+int32_t madqp_dist_unique_id(madqp_ctx* ctx, void* id128);
+/* nccl_id128: the 128 bytes of madqp_dist_unique_id (ignored when world == 1 or ops != NULL); ops: NULL = RCCL */
+int32_t madqp_dist_create(madqp_ctx* ctx, int32_t rank, int32_t world, int32_t P, int32_t Q, int64_t n, int64_t nb,
+                          const void* nccl_id128, const madqp_comm_ops* ops, madqp_dist** out);
+int32_t madqp_dist_destroy(madqp_dist* d);
+/* out8 = (p, q, local tile rows, local tile columns, local rows, local columns, leading dimension, padded columns) */
+int32_t madqp_dist_layout(madqp_dist* d, int64_t* out8);
+int32_t madqp_dist_matrix(madqp_dist* d, double** Kloc, int64_t* ld);
+int32_t madqp_dist_factor(madqp_dist* d, int32_t* info_host);
+int32_t madqp_dist_solve(madqp_dist* d, double* rhs);
+int32_t madqp_dist_bytes_sent(madqp_dist* d, int64_t* bytes_host);
+
 /* ----------------------------------------- native driver of one MPC iteration */
 /* The loop body of mpc! (src/solver.jl:254-345) above the entry points of this header, for hosts
  * that want one foreign call per iteration (small problems, batches).  The Julia glue does not

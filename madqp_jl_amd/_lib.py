@@ -148,6 +148,14 @@ _SIGNATURES = {
     "madqp_chol_panel_pack": [vp, i64, i64, vp],
     "madqp_chol_panel_unpack": [vp, i64, i64, vp],
     "madqp_chol_factor_end": [vp, pi32],
+    "madqp_dist_unique_id": [vp, vp],
+    "madqp_dist_create": [vp, i32, i32, i32, i32, i64, i64, vp, vp, C.POINTER(vp)],
+    "madqp_dist_destroy": [vp],
+    "madqp_dist_layout": [vp, pi64],
+    "madqp_dist_matrix": [vp, C.POINTER(vp), pi64],
+    "madqp_dist_factor": [vp, pi32],
+    "madqp_dist_solve": [vp, vp],
+    "madqp_dist_bytes_sent": [vp, pi64],
     "madqp_batch_create": [vp, i64, i64, i64, i64, pi64, i64, vp, i64, vp, C.POINTER(CBatchData),
                            C.POINTER(CMpcOptions), C.POINTER(vp)],
     "madqp_batch_destroy": [vp],

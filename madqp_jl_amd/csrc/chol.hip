@@ -977,6 +977,26 @@ extern "C" int32_t madqp_chol_factor_end(madqp_chol* s, int32_t* info_host) {
     return MADQP_OK;
 }
 
+// One sweep over a single order-w tile (multi-GPU solves, dist.hip): the same kernels as madqp_chol_solve.
+int32_t madqp_trsv_tile(madqp_ctx* ctx, int32_t trans, const double* L, int64_t ld, const double* winv, double* v,
+                        int64_t w, double* tmp, int32_t* ctl) {
+    ARG_TRY(ctx, L && winv && v && tmp && ctl && w > 0 && ld >= w);
+    ProfScope ps(ctx, MADQP_PROF_TRSV);
+    const unsigned nblk = (unsigned)((w + NB - 1) / NB);
+    const int vec = ((((uintptr_t)L) & 15) == 0) && (ld % 2 == 0);
+    HIP_TRY(ctx, hipMemsetAsync(ctl, 0, 4 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)tmp, 0x7FF8A5A5, 2 * (size_t)w, ctx->stream));
+    if (!trans)
+        hipLaunchKernelGGL(trsv_fwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, L, ld, winv, v, tmp, w, ctl,
+                           ctx->d_res + MADQP_FAULT_SLOT, vec);
+    else
+        hipLaunchKernelGGL(trsv_bwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, L, ld, winv, v, tmp, w, ctl,
+                           ctx->d_res + MADQP_FAULT_SLOT, vec);
+    LAUNCH_CHECK(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(v, tmp, (size_t)w * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return MADQP_OK;
+}
+
 extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
     if (!s) return MADQP_ERR_ARG;
     madqp_ctx* ctx = s->ctx;

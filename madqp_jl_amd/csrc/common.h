@@ -105,6 +105,9 @@ struct GemmArgs {
                            // multiple of 128 let edge tiles take the fast path, stores stay masked to M, N
     int64_t diag_off;  // global_row(i) - global_col(j) = i - j + diag_off
     int lower_only;    // 1: write only elements with i + diag_off >= j; skip tiles above
+    const int64_t* tile_row0;  // optional HOST array, one entry per 128-column tile of C: the first 128-row tile that is
+                               // computed in that tile column (block-cyclic local matrices: "global tile row >= global
+                               // tile column" is a per-column suffix, not an affine rule); whole tiles are written
 };
 // cols: optional host list of ncols column ranges [cols[2r], cols[2r+1]) (multiples of 128 relative to
 // C) -- only output tiles whose columns fall in one of them are computed (multi-GPU path: the block
@@ -137,6 +140,11 @@ int32_t madqp_spmv_csr(madqp_ctx* ctx, int64_t rows, const int64_t* rowptr, cons
 int32_t madqp_sparse_gram(madqp_ctx* ctx, int64_t n, const int64_t* rowptr, const int64_t* col, const double* val,
                           const int64_t* t_ptr, const int64_t* t_col, const double* t_val, const double* w,
                           const double* base, int64_t ldbase, const double* dvec, double* C, int64_t ldc);
+
+// chol.hip: one triangular sweep over an order-w tile whose factor and inverse diagonal blocks are given (dist.hip):
+// trans = 0: v <- L^-1 v, trans = 1: v <- L^-T v.  tmp: w doubles, ctl: 4 ints of device scratch.
+int32_t madqp_trsv_tile(madqp_ctx* ctx, int32_t trans, const double* L, int64_t ld, const double* winv, double* v,
+                        int64_t w, double* tmp, int32_t* ctl);
 
 struct madqp_chol {
     madqp_ctx* ctx;

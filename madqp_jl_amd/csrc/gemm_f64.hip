@@ -451,6 +451,12 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
         for (int64_t r = 0; r < ncols; ++r)
             for (int64_t t = cols[2 * r] / BN; t < (cols[2 * r + 1] + BN - 1) / BN; ++t) col_on[(size_t)t] = 1;
     }
+    if (a.tile_row0) {  // per-column first active tile row: part of the table's identity
+        ARG_TRY(ctx, !cols && !a.lower_only);
+        cols_hash = 1469598103934665603ull ^ 0x9E3779B97F4A7C15ull;
+        for (int64_t t = 0; t < tiles_n; ++t) cols_hash = (cols_hash ^ (uint64_t)a.tile_row0[t]) * 1099511628211ull;
+        if (cols_hash == 0) cols_hash = 1;
+    }
     // diag_off in tile units must be exact for the tile-skip test used when building the table
     TableKey key{tiles_m, tiles_n,
                  (a.lower_only ? 1 : 0) | ((a.M % BM) != 0 ? 2 : 0) | ((a.N % BN) != 0 ? 4 : 0),
@@ -469,6 +475,7 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
         const bool m_edge = (a.M % BM) != 0, n_edge = (a.N % BN) != 0;
         auto active = [&](int64_t tm, int64_t tn) {
             if (cols && !col_on[(size_t)tn]) return false;
+            if (a.tile_row0 && tm < a.tile_row0[tn]) return false;
             return !(a.lower_only && (tm * BM + BM - 1 + a.diag_off < tn * BN));
         };
         auto is_edge = [&](int64_t tm, int64_t tn) {

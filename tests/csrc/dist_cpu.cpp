@@ -1,0 +1,189 @@
+// TEST INFRASTRUCTURE -- not part of the product, never loaded by madqp_jl_amd/.
+//
+// The distributed schedule of madqp_jl_amd/csrc/dist_core.inc (2-D block-cyclic Cholesky + sweeps) compiled with
+// plain C++ loops in place of the rank-local HIP kernels and with the caller's host-staged collectives, so that the
+// CPU suite (`-m "not gpu"`) can run the REAL orchestration with world_size 2..6 over gloo (tests/test_dist2d.py).
+// "Device" memory is host memory here.  Built by tests/csrc/Makefile into tests/_build/libmadqp_dist_cpuref.so.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/madqp.h"
+
+struct Dev {
+    int dummy;
+};
+
+static void* dop_alloc(Dev*, size_t bytes) { return calloc(1, bytes); }
+static void dop_free(Dev*, void* p) { free(p); }
+static int32_t dop_sync(Dev*) { return 0; }
+static int32_t dop_h2d(Dev*, void* dst, const void* src, size_t bytes) {
+    memcpy(dst, src, bytes);
+    return 0;
+}
+static int32_t dop_d2h(Dev*, void* dst, const void* src, size_t bytes) {
+    memcpy(dst, src, bytes);
+    return 0;
+}
+static int32_t dop_zero(Dev*, double* p, int64_t count) {
+    if (count > 0) memset(p, 0, (size_t)count * sizeof(double));
+    return 0;
+}
+static int32_t dop_copy(Dev*, double* dst, const double* src, int64_t count) {
+    if (count > 0) memcpy(dst, src, (size_t)count * sizeof(double));
+    return 0;
+}
+static int32_t dop_copy2d(Dev*, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) {
+    for (int64_t c = 0; c < cols; ++c)
+        if (rows > 0) memcpy(dst + c * ldd, src + c * lds, (size_t)rows * sizeof(double));
+    return 0;
+}
+static int32_t dop_info_store(Dev*, const double* info, double* hdr) {
+    hdr[0] = *info;
+    hdr[1] = 0.0;
+    return 0;
+}
+static int32_t dop_info_merge(Dev*, double* info, const double* hdr) {
+    if (*info == 0.0 && hdr[0] != 0.0) *info = hdr[0];
+    return 0;
+}
+static int32_t dop_vsub(Dev*, double* a, const double* b, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) a[i] -= b[i];
+    return 0;
+}
+// C = beta C + alpha X Y' on the 128-tiles (ti, tj) with ti >= row0[tj]; the padded rows / columns that the HIP kernel
+// may READ (Mread, Nread) must be inside the buffers: touch them so that a wrong extent shows up under a sanitizer
+static int32_t dop_gemm(Dev*, double* C, int64_t ldc, const double* X, int64_t ldx, const double* Y, int64_t ldy, int64_t M,
+                        int64_t N, int64_t K, double alpha, double beta, int64_t Mread, int64_t Nread, const int64_t* row0) {
+    volatile double sink = 0.0;
+    if (K > 0 && Mread > 0) sink = X[(Mread - 1) + (K - 1) * ldx];
+    if (K > 0 && Nread > 0) sink = Y[(Nread - 1) + (K - 1) * ldy];
+    (void)sink;
+    for (int64_t j = 0; j < N; ++j) {
+        const int64_t i0 = row0 ? row0[j / 128] * 128 : 0;
+        for (int64_t i = i0; i < M; ++i) {
+            double s = 0.0;
+            for (int64_t k = 0; k < K; ++k) s += X[i + k * ldx] * Y[j + k * ldy];
+            C[i + j * ldc] = (beta != 0.0 ? beta * C[i + j * ldc] : 0.0) + alpha * s;
+        }
+    }
+    return 0;
+}
+static int32_t dop_potrf_tile(Dev*, double* T, int64_t ld, int64_t w, double* buf, int64_t col0, double* info) {
+    double first = 0.0;
+    for (int64_t j = 0; j < w; ++j) {
+        double d = T[j + j * ld];
+        for (int64_t k = 0; k < j; ++k) d -= T[j + k * ld] * T[j + k * ld];
+        if (!(d > 0.0)) {  // as the device kernel: record the first failing column, go on with a unit pivot
+            if (first == 0.0) first = (double)(col0 + j + 1);
+            d = 1.0;
+        }
+        const double l = std::sqrt(d);
+        T[j + j * ld] = l;
+        for (int64_t i = j + 1; i < w; ++i) {
+            double v = T[i + j * ld];
+            for (int64_t k = 0; k < j; ++k) v -= T[i + k * ld] * T[j + k * ld];
+            T[i + j * ld] = v / l;
+        }
+    }
+    const int64_t nblk = (w + 127) / 128;
+    buf[0] = first;
+    buf[1] = 0.0;
+    memset(buf + 2, 0, (size_t)(nblk * 2 * 128 * 128) * sizeof(double));  // inverse blocks: not used by these loops
+    double* L = buf + 2 + nblk * 2 * 128 * 128;
+    for (int64_t j = 0; j < w; ++j)
+        for (int64_t i = 0; i < w; ++i) L[i + j * w] = T[i + j * ld];
+    if (*info == 0.0 && first != 0.0) *info = first;
+    return 0;
+}
+static int32_t dop_trsm(Dev*, double* X, int64_t ldx, int64_t rows, int64_t, const double* L, int64_t ldl, const double*,
+                        int64_t w) {
+    for (int64_t i = 0; i < rows; ++i)
+        for (int64_t j = 0; j < w; ++j) {
+            double v = X[i + j * ldx];
+            for (int64_t k = 0; k < j; ++k) v -= X[i + k * ldx] * L[j + k * ldl];
+            X[i + j * ldx] = v / L[j + j * ldl];
+        }
+    return 0;
+}
+// madqp_gemv semantics: A has `rows` rows of length `cols`, row r at A + r*lda
+static int32_t dop_gemv(Dev*, int32_t trans, int64_t rows, int64_t cols, double alpha, const double* A, int64_t lda,
+                        const double* x, double beta, double* y) {
+    if (!trans) {
+        for (int64_t r = 0; r < rows; ++r) {
+            double s = 0.0;
+            for (int64_t c = 0; c < cols; ++c) s += A[r * lda + c] * x[c];
+            y[r] = (beta != 0.0 ? beta * y[r] : 0.0) + alpha * s;
+        }
+    } else {
+        for (int64_t c = 0; c < cols; ++c) {
+            double s = 0.0;
+            for (int64_t r = 0; r < rows; ++r) s += A[r * lda + c] * x[r];
+            y[c] = (beta != 0.0 ? beta * y[c] : 0.0) + alpha * s;
+        }
+    }
+    return 0;
+}
+static int32_t dop_tile_solve(Dev*, int32_t trans, const double* L, int64_t ld, const double*, double* v, int64_t w,
+                              double*) {
+    if (!trans) {
+        for (int64_t i = 0; i < w; ++i) {
+            double s = v[i];
+            for (int64_t k = 0; k < i; ++k) s -= L[i + k * ld] * v[k];
+            v[i] = s / L[i + i * ld];
+        }
+    } else {
+        for (int64_t i = w - 1; i >= 0; --i) {
+            double s = v[i];
+            for (int64_t k = i + 1; k < w; ++k) s -= L[k + i * ld] * v[k];
+            v[i] = s / L[i + i * ld];
+        }
+    }
+    return 0;
+}
+static int32_t dop_phase(Dev*, int) { return 0; }
+static int32_t dop_nccl_bcast(Dev*, void*, double*, int64_t, int) { return MADQP_ERR_STATE; }
+static int32_t dop_nccl_reduce(Dev*, void*, double*, int64_t, int) { return MADQP_ERR_STATE; }
+static int32_t dop_nccl_allreduce(Dev*, void*, double*, int64_t) { return MADQP_ERR_STATE; }
+
+#include "../../madqp_jl_amd/csrc/dist_core.inc"
+
+extern "C" {
+int32_t madqp_distcpu_create(int32_t rank, int32_t world, int32_t P, int32_t Q, int64_t n, int64_t nb,
+                             const madqp_comm_ops* ops, madqp_dist** out) {
+    if (!out || (world > 1 && !ops)) return MADQP_ERR_ARG;
+    Dev* dev = new Dev();
+    int32_t r = distcore::create(dev, rank, world, P, Q, n, nb, ops, out);
+    if (r) {
+        distcore::destroy(*out);
+        *out = nullptr;
+        delete dev;
+    }
+    return r;
+}
+int32_t madqp_distcpu_destroy(madqp_dist* d) {
+    if (!d) return 0;
+    Dev* dev = d->dev;
+    distcore::destroy(d);
+    delete dev;
+    return 0;
+}
+int32_t madqp_distcpu_layout(madqp_dist* d, int64_t* out8) {
+    const int64_t v[8] = {d->p, d->q, d->mt, d->nt, d->mloc, d->nloc, d->ld, d->ncp};
+    memcpy(out8, v, sizeof(v));
+    return 0;
+}
+int32_t madqp_distcpu_matrix(madqp_dist* d, double** K, int64_t* ld) {
+    *K = d->K;
+    *ld = d->ld;
+    return 0;
+}
+int32_t madqp_distcpu_factor(madqp_dist* d, int32_t* info) { return distcore::factor(d, info); }
+int32_t madqp_distcpu_solve(madqp_dist* d, double* rhs) { return distcore::solve(d, rhs); }
+int32_t madqp_distcpu_bytes_sent(madqp_dist* d, int64_t* b) {
+    *b = d->bytes_sent;
+    return 0;
+}
+}
