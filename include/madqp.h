@@ -98,6 +98,15 @@ int32_t madqp_gen_normal(madqp_ctx* ctx, uint64_t key, uint64_t idx0, int64_t co
 int32_t madqp_gen_wigner(madqp_ctx* ctx, uint64_t key, int64_t n, double inv_sqrt_n, double* H,
                          int64_t ld);
 
+/* the same data as the block-cyclic pieces one rank of a P x Q grid holds (madqp_dist_*, madqp_dkkt_*): local column c of
+ * a direction with modulus R and residue r is global column ((c / nb) * R + r) * nb + c % nb.
+ * gen_normal_cyclic: out[k*ldo + c] = A[k, global(c)] (m rows; entries beyond nx are 0);
+ * gen_wigner_cyclic: H[i + j*ld] = H[global_P(i), global_Q(j)], all local tiles complete (both triangles). */
+int32_t madqp_gen_normal_cyclic(madqp_ctx* ctx, uint64_t key, int64_t m, int64_t nx, int64_t nb, int32_t R, int32_t r,
+                                int64_t ncols_local, double* out, int64_t ldo);
+int32_t madqp_gen_wigner_cyclic(madqp_ctx* ctx, uint64_t key, int64_t n, double inv_sqrt_n, int64_t nb, int32_t P,
+                                int32_t p, int32_t Q, int32_t q, int64_t mloc, int64_t nloc, double* H, int64_t ld);
+
 /* ------------------------------------------------------- dense linear algebra */
 /* C(lower) = base(lower, may be NULL) + diag(dvec, may be NULL) + B' diag(w) B
  * B: kdim rows of length n (row k at B + k*ldb); w may be NULL (= ones).
@@ -377,6 +386,29 @@ int32_t madqp_dist_matrix(madqp_dist* d, double** Kloc, int64_t* ld);
 int32_t madqp_dist_factor(madqp_dist* d, int32_t* info_host);
 int32_t madqp_dist_solve(madqp_dist* d, double* rhs);
 int32_t madqp_dist_bytes_sent(madqp_dist* d, int64_t* bytes_host);
+
+/* The condensed KKT system K = H + Sigma_x + A' Theta A (madqp_kkt_create) with K on the grid of `d` (order nx): the
+ * same plugin methods -- build_kkt! / factorize! / solve! / mul! / jtprod! (src/KKT/normalkkt.jl:162-219) and the
+ * model callbacks (src/solver.jl:166-169,338-340) -- for one QP shared by all ranks.  A rank holds (borrowed, device):
+ *   Hloc  its tiles of H in the layout of the local K (ldh >= leading dimension of madqp_dist_layout; lower tiles,
+ *         diagonal tiles complete), or NULL for an LP;
+ *   A_I   the columns of A of its tile ROWS:    ceil16(m) rows of length ld_ai >= ld, row k contiguous, zero padded;
+ *   A_J   the columns of A of its tile COLUMNS: ceil16(m) rows of length ld_aj >= padded column count, zero padded
+ * i.e. 2/(PQ) of H and K and (1/P + 1/Q) of A (C5 on 2 x 4: 52 GB per rank instead of 224 GB).  Assembly needs no
+ * communication; iterates and scalars are replicated (madqp_state as for madqp_kkt_*), products with A, A', H are
+ * summed with one all-reduce each, so every rank sees bitwise the same vectors and scalars. */
+typedef struct madqp_dkkt madqp_dkkt;
+int32_t madqp_dkkt_create(madqp_dist* d, int64_t nx, int64_t m, int64_t ns, const int64_t* ind_ineq_host,
+                          const double* Hloc, int64_t ldh, const double* A_I, int64_t ld_ai, const double* A_J,
+                          int64_t ld_aj, madqp_dkkt** out);
+int32_t madqp_dkkt_destroy(madqp_dkkt* kkt);
+int32_t madqp_dkkt_build(madqp_dkkt* kkt, const madqp_state* st);
+int32_t madqp_dkkt_factorize(madqp_dkkt* kkt, int32_t* info_host);
+int32_t madqp_dkkt_solve(madqp_dkkt* kkt, const madqp_state* st, double* w);
+int32_t madqp_dkkt_mul(madqp_dkkt* kkt, const madqp_state* st, double* w, const double* v, double alpha, double beta);
+int32_t madqp_dkkt_jtprod(madqp_dkkt* kkt, double* out, const double* y);
+int32_t madqp_dkkt_eval(madqp_dkkt* kkt, const madqp_state* st, const double* q, const double* rhs, double c0,
+                        double* obj_host);
 
 /* ----------------------------------------- native driver of one MPC iteration */
 /* The loop body of mpc! (src/solver.jl:254-345) above the entry points of this header, for hosts

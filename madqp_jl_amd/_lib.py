@@ -156,6 +156,16 @@ _SIGNATURES = {
     "madqp_dist_factor": [vp, pi32],
     "madqp_dist_solve": [vp, vp],
     "madqp_dist_bytes_sent": [vp, pi64],
+    "madqp_dkkt_create": [vp, i64, i64, i64, pi64, vp, i64, vp, i64, vp, i64, C.POINTER(vp)],
+    "madqp_dkkt_destroy": [vp],
+    "madqp_dkkt_build": [vp, pstate],
+    "madqp_dkkt_factorize": [vp, pi32],
+    "madqp_dkkt_solve": [vp, pstate, vp],
+    "madqp_dkkt_mul": [vp, pstate, vp, vp, f64, f64],
+    "madqp_dkkt_jtprod": [vp, vp, vp],
+    "madqp_dkkt_eval": [vp, pstate, vp, vp, f64, pf64],
+    "madqp_gen_normal_cyclic": [vp, C.c_uint64, i64, i64, i64, i32, i32, i64, vp, i64],
+    "madqp_gen_wigner_cyclic": [vp, C.c_uint64, i64, f64, i64, i32, i32, i32, i32, i64, i64, vp, i64],
     "madqp_batch_create": [vp, i64, i64, i64, i64, pi64, i64, vp, i64, vp, C.POINTER(CBatchData),
                            C.POINTER(CMpcOptions), C.POINTER(vp)],
     "madqp_batch_destroy": [vp],

@@ -63,6 +63,7 @@ struct Dev {
     int64_t nb, wlast;
     int32_t* ctl;           // 4 ints: tile sweeps
     bool two_streams;
+    int prof_cls;           // timer class of the masked GEMM (panel updates, or the assembly)
 };
 
 #define NCCL_TRY(dev, expr)                                                                                    \
@@ -150,8 +151,9 @@ int32_t dop_vsub(Dev* dev, double* a, const double* b, int64_t n) {
 
 // ---- rank-local linear algebra
 // C = beta C + alpha X Y' on the 128-tiles (ti, tj) with ti >= row0[tj]
-int32_t dop_gemm(Dev* dev, double* C, int64_t ldc, const double* X, int64_t ldx, const double* Y, int64_t ldy, int64_t M,
-                 int64_t N, int64_t K, double alpha, double beta, int64_t Mread, int64_t Nread, const int64_t* row0) {
+int32_t dop_gemm(Dev* dev, double* C, int64_t ldc, const double* Cin, int64_t ldcin, const double* X, int64_t ldx,
+                 const double* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, double alpha, double beta, int64_t Mread,
+                 int64_t Nread, const int64_t* row0) {
     GemmArgs g{};
     g.X = X;
     g.ldx = ldx;
@@ -159,8 +161,8 @@ int32_t dop_gemm(Dev* dev, double* C, int64_t ldc, const double* X, int64_t ldx,
     g.ldy = ldy;
     g.C = C;
     g.ldc = ldc;
-    g.Cin = (beta != 0.0) ? C : nullptr;
-    g.ldcin = ldc;
+    g.Cin = (beta != 0.0) ? Cin : nullptr;
+    g.ldcin = ldcin;
     g.alpha = alpha;
     g.beta = beta;
     g.M = M;
@@ -169,7 +171,7 @@ int32_t dop_gemm(Dev* dev, double* C, int64_t ldc, const double* X, int64_t ldx,
     g.Mread = std::max(M, std::min(Mread, (M + 127) / 128 * 128));
     g.Nread = std::max(N, std::min(Nread, (N + 127) / 128 * 128));
     g.tile_row0 = row0;
-    return madqp_gemm_tn(dev->ctx, g, MADQP_PROF_POTRF_GEMM);
+    return madqp_gemm_tn(dev->ctx, g, dev->prof_cls);
 }
 
 // Cholesky of the w x w diagonal tile at T (in place); buf <- [info, 0 | inverse 128-blocks | L (w x w, ld w)];
@@ -343,6 +345,7 @@ extern "C" int32_t madqp_dist_create(madqp_ctx* ctx, int32_t rank, int32_t world
     dev->ctx = ctx;
     dev->main = ctx->stream;
     dev->nb = nb;
+    dev->prof_cls = MADQP_PROF_POTRF_GEMM;
     const int64_t T = (n + nb - 1) / nb;
     dev->wlast = T ? n - (T - 1) * nb : 0;
     static const int two = getenv("MADQP_DIST_STREAMS") ? atoi(getenv("MADQP_DIST_STREAMS")) : 1;
@@ -428,5 +431,389 @@ extern "C" int32_t madqp_dist_solve(madqp_dist* d, double* rhs) {
 extern "C" int32_t madqp_dist_bytes_sent(madqp_dist* d, int64_t* bytes_host) {
     if (!d || !bytes_host) return MADQP_ERR_ARG;
     *bytes_host = d->bytes_sent;
+    return MADQP_OK;
+}
+
+// =====================================================================================================
+// madqp_dkkt_*: the condensed KKT system K = H + Sigma_x + A' Theta A (kkt.hip) with K distributed over the grid.
+//
+// Same plugin methods as madqp_kkt_* (build_kkt! / factorize! / solve! / mul! / jtprod! and the model callbacks;
+// src/KKT/normalkkt.jl:162-219, src/solver.jl:166-169,338-340), same algebra.  What a rank holds:
+//   Hloc  its tiles of H, laid out like the local K (lower tiles; diagonal tiles complete, both triangles)
+//   A_I   the columns of A that belong to its tile ROWS   (m16 x ld, row k of A contiguous, zero padded)
+//   A_J   the columns of A that belong to its tile COLUMNS (m16 x ncp)
+// -- (1/(PQ) + 1/(PQ)) of H and K, (1/P + 1/Q) of A: nothing of order n^2 or m n is replicated.  Assembly needs no
+// communication: K_loc = Hloc + A_I' (Theta A_J) is one masked MFMA GEMM over the local lower tiles.  Iterates,
+// right-hand sides and every scalar are replicated (n + m doubles); products with A, A' and H are summed over the
+// ranks with ONE all-reduce each (every lower tile of H and every column block of A has exactly one owner, the
+// diagonal-tile owner of that block), so all ranks see bitwise identical vectors and take identical branches.
+#define TPB 256
+#define MADQP_MAX_BLOCKS 1024
+namespace {
+#define MQ_KERNEL __global__ __launch_bounds__(TPB) void
+#define MQ_BLOCK blockIdx.x
+#define GRID_STRIDE(i, len) \
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < (len); i += (int64_t)gridDim.x * TPB)
+inline int dk_grid(int64_t len) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>((len + TPB - 1) / TPB, MADQP_MAX_BLOCKS));
+}
+#include "kkt_kernels.inc"
+
+// S[k, :] = theta[k] * A[k, :] for k < m, zero rows up to m16
+__global__ __launch_bounds__(256) void dk_scale_rows_kernel(int64_t m, int64_t cols, const double* __restrict__ A, int64_t lda,
+                                                            const double* __restrict__ theta, double* __restrict__ S,
+                                                            int64_t lds) {
+    const int64_t k = blockIdx.y;
+    const double t = (k < m) ? theta[k] : 0.0;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cols; c += (int64_t)gridDim.x * 256)
+        S[k * lds + c] = (k < m) ? t * A[k * lda + c] : 0.0;
+}
+// K_loc[diag of local diagonal tile] += dvec[global index]
+__global__ __launch_bounds__(256) void dk_add_diag_kernel(int64_t ntile, const int64_t* __restrict__ tiles, int64_t nb,
+                                                          int64_t n, const double* __restrict__ dvec,
+                                                          double* __restrict__ K, int64_t ld) {
+    const int64_t t = blockIdx.y;
+    if (t >= ntile) return;
+    const int64_t li = tiles[3 * t], lj = tiles[3 * t + 1], I = tiles[3 * t + 2];
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nb; r += (int64_t)gridDim.x * 256) {
+        const int64_t g = I * nb + r;
+        if (g < n) K[(li * nb + r) + (lj * nb + r) * ld] += dvec[g];
+    }
+}
+// local-row order <-> global order: out_loc[li*nb + r] = x[(li*R + res)*nb + r]
+__global__ __launch_bounds__(256) void dk_gather_kernel(int64_t cnt, int64_t nb, int64_t R, int64_t res, int64_t n,
+                                                        const double* __restrict__ x, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = ((i / nb) * R + res) * nb + i % nb;
+        out[i] = (g < n) ? x[g] : 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void dk_scatter_add_kernel(int64_t cnt, int64_t nb, int64_t R, int64_t res, int64_t n,
+                                                             const double* __restrict__ loc, double alpha,
+                                                             double* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = ((i / nb) * R + res) * nb + i % nb;
+        if (g < n) y[g] += alpha * loc[i];
+    }
+}
+// w = alpha * g + beta * w  (beta == 0: w is not read)
+__global__ __launch_bounds__(256) void dk_axpby_kernel(int64_t n, double alpha, const double* __restrict__ g, double beta,
+                                                       double* __restrict__ w) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        w[i] = (beta == 0.0) ? alpha * g[i] : alpha * g[i] + beta * w[i];
+}
+}  // namespace
+
+struct madqp_dkkt {
+    madqp_dist* d;
+    madqp_ctx* ctx;
+    int64_t nx, m, ns, m16;
+    const double* H;  // local tiles (ldh) or nullptr
+    int64_t ldh;
+    const double *AI, *AJ;
+    int64_t ldai, ldaj;
+    double* SJ;          // Theta * A_J (m16 x ncp), owned
+    int64_t* d_ind_ineq; // ns
+    int64_t* d_slot;     // m
+    int64_t* d_diag;     // local diagonal tiles: (li, lj, I) triples
+    int64_t ndiag;
+    std::vector<int64_t> own_li;  // local tile rows whose A / H column block this rank owns for the mat-vecs
+    double *theta, *t, *u;        // m
+    double *gn, *gm;              // n + m contiguous: all-reduce buffer
+    double *xr, *yr, *yc;         // local-order scratch: mloc, mloc, nloc
+};
+
+#define DKL(kern, len, ...)                                                                       \
+    do {                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(dk_grid(len)), dim3(TPB), 0, ctx->stream, __VA_ARGS__);     \
+        LAUNCH_CHECK(ctx);                                                                        \
+    } while (0)
+
+extern "C" int32_t madqp_dkkt_destroy(madqp_dkkt* k) {
+    if (!k) return MADQP_OK;
+    (void)hipStreamSynchronize(k->ctx->stream);
+    void* ptrs[] = {k->SJ, k->d_ind_ineq, k->d_slot, k->d_diag, k->theta, k->t, k->u, k->gn, k->xr, k->yr, k->yc};
+    for (void* ptr : ptrs)
+        if (ptr) (void)hipFree(ptr);
+    delete k;
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_dkkt_create(madqp_dist* d, int64_t nx, int64_t m, int64_t ns, const int64_t* ind_ineq_host,
+                                     const double* Hloc, int64_t ldh, const double* A_I, int64_t ld_ai,
+                                     const double* A_J, int64_t ld_aj, madqp_dkkt** out) {
+    if (!d || !out) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = d->dev->ctx;
+    *out = nullptr;
+    ARG_TRY(ctx, nx == d->n && m >= 0 && ns >= 0 && ns <= m && (ns == 0 || ind_ineq_host));
+    ARG_TRY(ctx, !Hloc || ldh >= d->ld);
+    ARG_TRY(ctx, m == 0 || nx == 0 || (A_I && ld_ai >= d->ld && A_J && ld_aj >= d->ncp));
+    std::vector<int64_t> slot((size_t)std::max<int64_t>(m, 1), -1);
+    for (int64_t k = 0; k < ns; ++k) {
+        const int64_t r = ind_ineq_host[k];
+        ARG_TRY(ctx, r >= 0 && r < m && slot[r] < 0 && (k == 0 || ind_ineq_host[k - 1] < r));
+        slot[r] = k;
+    }
+    madqp_dkkt* k = new (std::nothrow) madqp_dkkt();
+    if (!k) return madqp_fail(ctx, MADQP_ERR_ALLOC, "host allocation failed");
+    k->d = d;
+    k->ctx = ctx;
+    k->nx = nx;
+    k->m = m;
+    k->ns = ns;
+    k->m16 = (m + 15) / 16 * 16;
+    k->H = Hloc;
+    k->ldh = ldh;
+    k->AI = A_I;
+    k->ldai = ld_ai;
+    k->AJ = A_J;
+    k->ldaj = ld_aj;
+    k->SJ = nullptr;
+    k->d_ind_ineq = k->d_slot = k->d_diag = nullptr;
+    k->theta = k->t = k->u = k->gn = k->gm = k->xr = k->yr = k->yc = nullptr;
+    std::vector<int64_t> diag;
+    for (int64_t li = 0; li < d->mt; ++li) {
+        const int64_t I = li * d->P + d->p;
+        if (I % d->Q == d->q) {
+            diag.insert(diag.end(), {li, I / d->Q, I});
+            k->own_li.push_back(li);
+        }
+    }
+    k->ndiag = (int64_t)diag.size() / 3;
+    const size_t mb = (size_t)std::max<int64_t>(m, 1) * sizeof(double);
+    hipError_t e = hipMalloc(&k->SJ, (size_t)std::max<int64_t>(k->m16 * d->ncp, 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&k->d_ind_ineq, (size_t)std::max<int64_t>(ns, 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&k->d_slot, (size_t)std::max<int64_t>(m, 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&k->d_diag, (size_t)std::max<int64_t>(3 * k->ndiag, 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&k->theta, mb);
+    if (e == hipSuccess) e = hipMalloc(&k->t, mb);
+    if (e == hipSuccess) e = hipMalloc(&k->u, mb);
+    if (e == hipSuccess) e = hipMalloc(&k->gn, (size_t)std::max<int64_t>(nx + m, 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&k->xr, (size_t)d->ld * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&k->yr, (size_t)d->ld * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&k->yc, (size_t)d->ncp * sizeof(double));
+    if (e == hipSuccess && ns) e = hipMemcpy(k->d_ind_ineq, ind_ineq_host, ns * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && m) e = hipMemcpy(k->d_slot, slot.data(), m * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && k->ndiag)
+        e = hipMemcpy(k->d_diag, diag.data(), diag.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        madqp_dkkt_destroy(k);
+        return madqp_fail(ctx, MADQP_ERR_ALLOC, "madqp_dkkt_create: %s", hipGetErrorString(e));
+    }
+    k->gm = k->gn + nx;
+    *out = k;
+    return MADQP_OK;
+}
+
+static int32_t dk_check(madqp_dkkt* k, const madqp_state* st) {
+    if (!k) return MADQP_ERR_ARG;
+    ARG_TRY(k->ctx, st && st->n == k->nx + k->ns && st->m == k->m);
+    return MADQP_OK;
+}
+
+// partial products of the blocks this rank owns, accumulated into the all-reduce buffers (which the caller zeroed):
+//   gn += alpha A' u (u: m),   gm += alpha A x (x: global order),   gn += alpha H x
+static int32_t dk_At_partial(madqp_dkkt* k, double alpha, const double* u) {
+    madqp_dist* d = k->d;
+    if (!k->m) return MADQP_OK;
+    for (int64_t li : k->own_li) {
+        const int64_t I = li * d->P + d->p, w = distcore::tsize(d, I);
+        int32_t r = madqp_gemv_impl(k->ctx, 1, k->m, w, alpha, k->AI + li * d->nb, k->ldai, u, 1.0, k->gn + I * d->nb,
+                                    MADQP_PROF_GEMV);
+        if (r) return r;
+    }
+    return MADQP_OK;
+}
+static int32_t dk_A_partial(madqp_dkkt* k, double alpha, const double* x) {
+    madqp_dist* d = k->d;
+    if (!k->m) return MADQP_OK;
+    for (int64_t li : k->own_li) {
+        const int64_t I = li * d->P + d->p, w = distcore::tsize(d, I);
+        int32_t r = madqp_gemv_impl(k->ctx, 0, k->m, w, alpha, k->AI + li * d->nb, k->ldai, x + I * d->nb, 1.0, k->gm,
+                                    MADQP_PROF_GEMV);
+        if (r) return r;
+    }
+    return MADQP_OK;
+}
+static int32_t dk_H_partial(madqp_dkkt* k, double alpha, const double* x) {
+    madqp_dist* d = k->d;
+    madqp_ctx* ctx = k->ctx;
+    if (!k->H || d->mloc == 0 || d->nloc == 0) return MADQP_OK;
+    const int64_t nb = d->nb;
+    {
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        DKL(dk_gather_kernel, d->mloc, d->mloc, nb, (int64_t)d->P, (int64_t)d->p, d->n, x, k->xr);
+        HIP_TRY(ctx, hipMemsetAsync(k->yr, 0, (size_t)d->mloc * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(k->yc, 0, (size_t)d->nloc * sizeof(double), ctx->stream));
+    }
+    for (int64_t lj = 0; lj < d->nt; ++lj) {
+        const int64_t J = lj * d->Q + d->q, w = distcore::tsize(d, J);
+        const int64_t li0 = (J > d->p) ? (J - d->p + d->P - 1) / d->P : 0;  // first local tile row with I >= J
+        if (li0 >= d->mt) continue;
+        const double* Pn = k->H + li0 * nb + lj * nb * k->ldh;
+        const int64_t rows = d->mloc - li0 * nb;
+        int32_t r = madqp_gemv_impl(ctx, 1, w, rows, 1.0, Pn, k->ldh, x + J * nb, 1.0, k->yr + li0 * nb, MADQP_PROF_GEMV);
+        if (r) return r;
+        const bool has_diag = (li0 * d->P + d->p == J);  // the diagonal tile is the first one of the panel
+        const int64_t skip = has_diag ? nb : 0;          // its transpose part is already in the product above
+        if (rows - skip > 0) {
+            r = madqp_gemv_impl(ctx, 0, w, rows - skip, 1.0, Pn + skip, k->ldh, k->xr + li0 * nb + skip, 1.0,
+                                k->yc + lj * nb, MADQP_PROF_GEMV);
+            if (r) return r;
+        }
+    }
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    DKL(dk_scatter_add_kernel, d->mloc, d->mloc, nb, (int64_t)d->P, (int64_t)d->p, d->n, k->yr, alpha, k->gn);
+    DKL(dk_scatter_add_kernel, d->nloc, d->nloc, nb, (int64_t)d->Q, (int64_t)d->q, d->n, k->yc, alpha, k->gn);
+    return MADQP_OK;
+}
+static int32_t dk_zero(madqp_dkkt* k, double* ptr, int64_t count) {
+    if (count > 0) HIP_TRY(k->ctx, hipMemsetAsync(ptr, 0, (size_t)count * sizeof(double), k->ctx->stream));
+    return MADQP_OK;
+}
+
+// MadNLP.build_kkt! (src/KKT/normalkkt.jl:166-180): Theta, then K_loc = H_loc + Sigma_x + A_I' (Theta A_J)
+extern "C" int32_t madqp_dkkt_build(madqp_dkkt* k, const madqp_state* st) {
+    int32_t r = dk_check(k, st);
+    if (r) return r;
+    madqp_ctx* ctx = k->ctx;
+    madqp_dist* d = k->d;
+    {
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        if (k->m) DKL(theta_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, k->theta);
+        if (k->m16 && d->nloc) {
+            const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((d->ncp + 255) / 256, 64));
+            hipLaunchKernelGGL(dk_scale_rows_kernel, dim3(gx, (unsigned)k->m16), dim3(256), 0, ctx->stream, k->m, d->ncp,
+                               k->AJ, k->ldaj, k->theta, k->SJ, d->ncp);
+            LAUNCH_CHECK(ctx);
+        }
+    }
+    if (k->m16 == 0 && d->mloc && d->nloc) {  // no constraints: K = H (+ diagonal)
+        if (k->H)
+            HIP_TRY(ctx, hipMemcpy2DAsync(d->K, (size_t)d->ld * sizeof(double), k->H, (size_t)k->ldh * sizeof(double),
+                                          (size_t)d->mloc * sizeof(double), (size_t)d->nloc, hipMemcpyDeviceToDevice,
+                                          ctx->stream));
+        else
+            HIP_TRY(ctx, hipMemset2DAsync(d->K, (size_t)d->ld * sizeof(double), 0, (size_t)d->mloc * sizeof(double),
+                                          (size_t)d->nloc, ctx->stream));
+    } else {
+        d->dev->prof_cls = MADQP_PROF_SYRK;
+        r = distcore::assemble_product(d, k->H, k->ldh, k->AI, k->ldai, k->SJ, d->ncp, k->m16);
+        d->dev->prof_cls = MADQP_PROF_POTRF_GEMM;
+        if (r) return r;
+    }
+    if (k->ndiag) {
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        hipLaunchKernelGGL(dk_add_diag_kernel, dim3((unsigned)std::min<int64_t>((d->nb + 255) / 256, 64), (unsigned)k->ndiag),
+                           dim3(256), 0, ctx->stream, k->ndiag, k->d_diag, d->nb, d->n, st->pr_diag, d->K, d->ld);
+        LAUNCH_CHECK(ctx);
+    }
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_dkkt_factorize(madqp_dkkt* k, int32_t* info_host) {
+    if (!k) return MADQP_ERR_ARG;
+    return madqp_dist_factor(k->d, info_host);
+}
+
+// MadNLP.solve!(kkt, w) (src/KKT/normalkkt.jl:182-205) with the condensed algebra of kkt.hip
+extern "C" int32_t madqp_dkkt_solve(madqp_dkkt* k, const madqp_state* st, double* w) {
+    int32_t r = dk_check(k, st);
+    if (r) return r;
+    madqp_ctx* ctx = k->ctx;
+    madqp_dist* d = k->d;
+    ARG_TRY(ctx, w != nullptr);
+    double* wx = w;
+    double* wy = w + st->n;
+    if ((r = madqp_reduce_rhs(ctx, st, w))) return r;
+    if (k->m) {
+        {
+            ProfScope ps(ctx, MADQP_PROF_VEC);
+            DKL(condense_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, k->theta, wx, wy, k->t, k->u);
+        }
+        if ((r = dk_zero(k, k->gn, k->nx)) || (r = dk_At_partial(k, 1.0, k->u))) return r;
+        if ((r = distcore::comm_allreduce(d, k->gn, k->nx, GRP_WORLD))) return r;
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        DKL(dk_axpby_kernel, k->nx, k->nx, 1.0, k->gn, 1.0, wx);  // rhs_x = r1_x + A' (theta t)
+    }
+    if ((r = madqp_dist_solve(d, wx))) return r;
+    if (k->m) {
+        if ((r = dk_zero(k, k->gm, k->m)) || (r = dk_A_partial(k, 1.0, wx))) return r;
+        if ((r = distcore::comm_allreduce(d, k->gm, k->m, GRP_WORLD))) return r;
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        DKL(decondense_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, k->theta, k->t, k->gm, wx, wy);
+    }
+    return madqp_finish_aug_solve(ctx, st, w);
+}
+
+// MadNLP.jtprod!(out, kkt, y) (src/KKT/normalkkt.jl:162-164): out(n) = [A' y ; -y[ind_ineq]]
+extern "C" int32_t madqp_dkkt_jtprod(madqp_dkkt* k, double* out, const double* y) {
+    if (!k) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = k->ctx;
+    ARG_TRY(ctx, (out || k->nx + k->ns == 0) && (y || k->m == 0));
+    int32_t r;
+    if ((r = dk_zero(k, k->gn, k->nx)) || (r = dk_At_partial(k, 1.0, y))) return r;
+    if ((r = distcore::comm_allreduce(k->d, k->gn, k->nx, GRP_WORLD))) return r;
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    if (k->nx) DKL(dk_axpby_kernel, k->nx, k->nx, 1.0, k->gn, 0.0, out);
+    if (k->ns) DKL(jt_slack_kernel, k->ns, k->ns, k->d_ind_ineq, y, out + k->nx, 1.0, 0.0);
+    return MADQP_OK;
+}
+
+// MadNLP.mul!(w, kkt, v, alpha, beta) (src/KKT/normalkkt.jl:207-219) with H for a QP
+extern "C" int32_t madqp_dkkt_mul(madqp_dkkt* k, const madqp_state* st, double* w, const double* v, double alpha,
+                                  double beta) {
+    int32_t r = dk_check(k, st);
+    if (r) return r;
+    madqp_ctx* ctx = k->ctx;
+    ARG_TRY(ctx, w && v);
+    const int64_t nx = k->nx, n = st->n;
+    // gn = A' vy + H vx, gm = A vx: one all-reduce of n_x + m doubles
+    if ((r = dk_zero(k, k->gn, nx + k->m)) || (r = dk_At_partial(k, 1.0, v + n)) || (r = dk_H_partial(k, 1.0, v)) ||
+        (r = dk_A_partial(k, 1.0, v)))
+        return r;
+    if ((r = distcore::comm_allreduce(k->d, k->gn, nx + k->m, GRP_WORLD))) return r;
+    {
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        if (nx) DKL(dk_axpby_kernel, nx, nx, alpha, k->gn, beta, w);
+        if (k->ns) DKL(jt_slack_kernel, k->ns, k->ns, k->d_ind_ineq, v + n, w + nx, alpha, beta);
+        if (k->m) DKL(mul_rows_kernel, k->m, k->m, k->d_slot, k->gm, v + nx, w + n, alpha, beta);
+    }
+    return madqp_kktmul(ctx, st, w, v, alpha, beta);
+}
+
+// model callbacks (src/solver.jl:166-169,338-340): f = [H x + q ; 0], c = A x - s - rhs, obj = c0 + q'x + x'Hx/2
+extern "C" int32_t madqp_dkkt_eval(madqp_dkkt* k, const madqp_state* st, const double* q, const double* rhs, double c0,
+                                   double* obj_host) {
+    int32_t r = dk_check(k, st);
+    if (r) return r;
+    madqp_ctx* ctx = k->ctx;
+    ARG_TRY(ctx, obj_host && (k->nx == 0 || q) && (k->m == 0 || rhs));
+    const int64_t nx = k->nx, n = st->n;
+    if ((r = dk_zero(k, k->gn, nx + k->m)) || (r = dk_H_partial(k, 1.0, st->x)) || (r = dk_A_partial(k, 1.0, st->x)))
+        return r;
+    if ((r = distcore::comm_allreduce(k->d, k->gn, nx + k->m, GRP_WORLD))) return r;
+    double sums[2] = {0.0, 0.0};
+    if (n) {
+        const int nb = dk_grid(n);
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        if (k->H && nx) DKL(dk_axpby_kernel, nx, nx, 1.0, k->gn, 0.0, st->f);
+        hipLaunchKernelGGL(eval_grad_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, n, nx, (k->H && nx) ? 1 : 0, q, st->x,
+                           st->f, ctx->d_part);
+        LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(sum2_final_kernel, dim3(1), dim3(TPB), 0, ctx->stream, ctx->d_part, nb, ctx->d_res);
+        LAUNCH_CHECK(ctx);
+    }
+    if (k->m) {
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        DKL(dk_axpby_kernel, k->m, k->m, 1.0, k->gm, 0.0, st->c);
+        DKL(eval_cons_kernel, k->m, k->m, k->d_slot, st->x + nx, rhs, st->c);
+    }
+    if (n) {
+        if ((r = madqp_read_results(ctx, 2, sums))) return r;
+    } else if ((r = madqp_ctx_sync(ctx))) {
+        return r;
+    }
+    *obj_host = c0 + sums[0] + 0.5 * sums[1];
     return MADQP_OK;
 }

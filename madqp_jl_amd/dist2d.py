@@ -164,3 +164,184 @@ class DistCholesky2D:
         if self._h is not None:
             self.be.lib.madqp_dist_destroy(self._h)
             self._h = None
+
+
+# =====================================================================================================
+# One QP shared by all ranks: what a rank holds of it, and the KKT system above madqp_dkkt_*
+def _cyclic_index(count_local, nb, R, r, device):
+    """Global index of every local row / column of a direction with modulus R and residue r."""
+    c = torch.arange(count_local, device=device)
+    return (c // nb * R + r) * nb + c % nb
+
+
+class DistributedQP:
+    """A dense QP ``min x'Hx/2 + q'x  s.t. lcon <= Ax <= ucon, lvar <= x <= uvar`` whose matrices are spread over the
+    grid of a :class:`DistCholesky2D` (the vectors are replicated): ``Hloc`` -- the tiles of H in the local layout of K
+    (tensor ``(ncp, ld)``, entry (i, j) of the local matrix at ``[j, i]``: column-major), ``A_I`` / ``A_J`` -- the
+    columns of A of this rank's tile rows / tile columns (``(ceil16(m), ld)`` / ``(ceil16(m), ncp)``, zero padded)."""
+
+    def __init__(self, grid, Hloc, q, A_I, A_J, lvar, uvar, lcon, ucon, x0, c0=0.0, y0=None, name="distributed-qp"):
+        self.grid, self.H, self.q, self.A_I, self.A_J = grid, Hloc, q, A_I, A_J
+        self.lvar, self.uvar, self.lcon, self.ucon, self.x0, self.c0, self.name = lvar, uvar, lcon, ucon, x0, float(c0), name
+        self.y0 = y0 if y0 is not None else torch.zeros_like(lcon)
+        self.A = None  # there is no full A anywhere
+
+    nvar = property(lambda s: s.q.numel())
+    ncon = property(lambda s: s.lcon.numel())
+
+    def eliminate_fixed(self):
+        return None
+
+    @classmethod
+    def synthetic(cls, backend, grid, seed: int, n: int, m: int, family: str = "wigner"):
+        """The benchmark family of :meth:`DeviceQP.synthetic`, every rank generating only its own pieces (the
+        generator is position addressable: bit for bit the entries of the one-GPU problem)."""
+        import math
+
+        from .qp import STREAM_A, STREAM_H, STREAM_Q, stream_key
+
+        assert n == grid.n
+        dev, f64 = backend.device, torch.float64
+        m16 = (m + 15) // 16 * 16
+        A_I = torch.zeros((max(m16, 1), grid.ld), dtype=f64, device=dev)
+        A_J = torch.zeros((max(m16, 1), grid.ncp), dtype=f64, device=dev)
+        kA = stream_key(seed, STREAM_A)
+        backend._ck(backend.lib.madqp_gen_normal_cyclic(backend.ctx, kA, m, n, grid.nb, grid.P, grid.p, grid.mloc,
+                                                        A_I.data_ptr(), grid.ld))
+        backend._ck(backend.lib.madqp_gen_normal_cyclic(backend.ctx, kA, m, n, grid.nb, grid.Q, grid.q, grid.nloc,
+                                                        A_J.data_ptr(), grid.ncp))
+        q = torch.empty(n, dtype=f64, device=dev)
+        backend.gen_normal(stream_key(seed, STREAM_Q), 0, q)
+        H = None
+        if family == "wigner":
+            H = torch.zeros((grid.ncp, grid.ld), dtype=f64, device=dev)
+            backend._ck(backend.lib.madqp_gen_wigner_cyclic(backend.ctx, stream_key(seed, STREAM_H), n, 1.0 / math.sqrt(n),
+                                                            grid.nb, grid.P, grid.p, grid.Q, grid.q, grid.mloc, grid.nloc,
+                                                            H.data_ptr(), grid.ld))
+        elif family != "lp":
+            raise ValueError(family)
+        z = lambda k, v: torch.full((k,), v, dtype=f64, device=dev)
+        return cls(grid, H, q, A_I, A_J, z(n, 0.0), z(n, 1.0), z(m, 0.0), z(m, 1.0), z(n, 0.0),
+                   name=f"synthetic-{family}-n{n}-m{m}-s{seed}-grid{grid.P}x{grid.Q}")
+
+    @classmethod
+    def from_dense(cls, backend, grid, H, q, A, lvar, uvar, lcon, ucon, x0, c0=0.0):
+        """Pieces of a QP given in full on the host (numpy; tests and small problems)."""
+        dev, f64 = backend.device, torch.float64
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+        n, m = len(q), A.shape[0]
+        assert n == grid.n
+        m16 = (m + 15) // 16 * 16
+        gi = _cyclic_index(grid.mloc, grid.nb, grid.P, grid.p, "cpu").numpy()
+        gj = _cyclic_index(grid.nloc, grid.nb, grid.Q, grid.q, "cpu").numpy()
+        A_I = torch.zeros((max(m16, 1), grid.ld), dtype=f64, device=dev)
+        A_J = torch.zeros((max(m16, 1), grid.ncp), dtype=f64, device=dev)
+        if m:
+            A_I[:m, :grid.mloc] = t(A[:, gi])
+            A_J[:m, :grid.nloc] = t(A[:, gj])
+        Hloc = None
+        if H is not None and np.any(H):
+            Hloc = torch.zeros((grid.ncp, grid.ld), dtype=f64, device=dev)
+            Hloc[:grid.nloc, :grid.mloc] = t(H[np.ix_(gi, gj)].T)
+        return cls(grid, Hloc, t(q), A_I, A_J, t(lvar), t(uvar), t(lcon), t(ucon), t(x0), c0)
+
+    # ---- the two places the set-up needs a product with the matrices before a KKT object exists (src/solver.jl:148-159)
+    def row_absmax(self):
+        """max_j |A[k, j]| per row, over all ranks."""
+        r = self.A_I[: self.ncon].abs().amax(dim=1) if self.ncon and self.grid.mloc else torch.zeros(self.ncon, dtype=torch.float64, device=self.q.device)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            c = r.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.MAX)
+            r = c.to(r.device)
+        return r
+
+    def hess_times(self, x):
+        """H x from the local tiles (each lower tile once, its mirror image too), summed over the ranks."""
+        g, n = self.grid, self.nvar
+        y = torch.zeros(n, dtype=torch.float64, device=x.device)
+        if self.H is not None and g.mloc and g.nloc:
+            gi = _cyclic_index(g.mloc, g.nb, g.P, g.p, x.device)
+            gj = _cyclic_index(g.nloc, g.nb, g.Q, g.q, x.device)
+            Hl = self.H[: g.nloc, : g.mloc]  # [j, i]
+            lower = (gi[None, :] // g.nb) >= (gj[:, None] // g.nb)  # tile row >= tile column
+            strict = (gi[None, :] // g.nb) > (gj[:, None] // g.nb)
+            y.index_add_(0, gi, (Hl * lower).t() @ x[gj])
+            y.index_add_(0, gj, (Hl * strict) @ x[gi])
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            c = y.cpu()
+            dist.all_reduce(c)
+            y = c.to(y.device)
+        return y
+
+
+class HIPDistributedCondensedKKTSystem2D:
+    """:class:`HIPCondensedKKTSystem` with ``K`` on a P x Q grid (``madqp_dkkt_*``): same methods, same fields."""
+
+    def __init__(self, backend, st, nx, ind_ineq, grid, Hloc, A_I, A_J):
+        from .kkt import HIPCholeskySolver
+
+        self.be, self.st, self.grid = backend, st, grid
+        self.nx, self.m = int(nx), st.m
+        self.ind_ineq = [int(i) for i in ind_ineq]
+        self.ns = len(self.ind_ineq)
+        assert st.n == self.nx + self.ns and grid.n == self.nx
+        self.H, self.A_I, self.A_J = Hloc, A_I, A_J  # keep the borrowed tensors alive
+        ineq = (C.c_int64 * max(self.ns, 1))(*self.ind_ineq)
+        h = C.c_void_p()
+        backend._ck(backend.lib.madqp_dkkt_create(grid._h, self.nx, self.m, self.ns, ineq,
+                                                  None if Hloc is None else Hloc.data_ptr(), grid.ld,
+                                                  A_I.data_ptr(), A_I.stride(0), A_J.data_ptr(), A_J.stride(0), C.byref(h)))
+        self._h = h
+        self.linear_solver = HIPCholeskySolver(backend, None)
+        self.linear_solver.factorize = self._factorize
+        self.n_factorizations = 0
+        self.panel_width = grid.nb
+
+    reg = property(lambda s: s.st.reg)
+    pr_diag = property(lambda s: s.st.pr_diag)
+    du_diag = property(lambda s: s.st.du_diag)
+
+    def close(self):
+        if self._h is not None:
+            self.be.lib.madqp_dkkt_destroy(self._h)
+            self._h = None
+
+    def initialize(self):
+        st, be = self.st, self.be
+        for t, v in ((st.reg, 1.0), (st.pr_diag, 1.0), (st.du_diag, 0.0), (st.l_lower, 0.0), (st.u_lower, 0.0),
+                     (st.l_diag, 1.0), (st.u_diag, 1.0)):
+            be.fill(v, t)
+
+    def set_aug_diagonal_reg(self, del_w, del_c):
+        self.be.set_aug_diagonal_reg(self.st, del_w, del_c)
+
+    def _factorize(self):
+        info = C.c_int32()
+        self.be._ck(self.be.lib.madqp_dkkt_factorize(self._h, C.byref(info)))
+        self.linear_solver.info = info.value
+        return self.linear_solver
+
+    def build_kkt(self):
+        self.be._ck(self.be.lib.madqp_dkkt_build(self._h, C.byref(self.st.cstruct)))
+
+    def factorize_wrapper(self):
+        self.build_kkt()
+        self._factorize()
+        self.n_factorizations += 1
+
+    def solve(self, w):
+        self.be._ck(self.be.lib.madqp_dkkt_solve(self._h, C.byref(self.st.cstruct), w.data_ptr()))
+        return w
+
+    def mul(self, w, v, alpha=1.0, beta=0.0):
+        self.be._ck(self.be.lib.madqp_dkkt_mul(self._h, C.byref(self.st.cstruct), w.data_ptr(), v.data_ptr(), alpha, beta))
+        return w
+
+    def jtprod(self, out, y):
+        self.be._ck(self.be.lib.madqp_dkkt_jtprod(self._h, out.data_ptr(), y.data_ptr()))
+
+    def eval_model(self, q, rhs, c0) -> float:
+        obj = C.c_double()
+        self.be._ck(self.be.lib.madqp_dkkt_eval(self._h, C.byref(self.st.cstruct), q.data_ptr(), rhs.data_ptr(), c0,
+                                                C.byref(obj)))
+        return obj.value

@@ -143,6 +143,8 @@ class MPCSolver:
         self.dnorm = 0.0
         if self.opt.driver not in ("python", "native"):
             raise ValueError(f"unknown driver {self.opt.driver!r}")
+        if hasattr(qp, "grid") and self.opt.driver == "native":
+            raise ValueError("the native driver factorizes on one GPU; a DistributedQP needs driver='python'")
         if self.opt.distributed and self.opt.driver == "native":
             raise ValueError("the native driver factorizes on one GPU; use driver='python' with distributed=True")
         self._native = None  # madqp_mpc handle (driver="native")
@@ -320,6 +322,12 @@ class MPCSolver:
         """``MadNLP.create_kkt_system(opt.kkt_system, cb, ind_cons, opt.linear_solver)`` (src/structure.jl:115-121) on
         the scaled model data; a seam for tests that swap the plugin types."""
         opt, be, st, nx = self.opt, self.be, self.st, self.nx
+        if hasattr(self.qp, "grid"):  # one QP over a P x Q grid of ranks (SURVEY.md 8e): madqp_dkkt_*
+            from .dist2d import HIPDistributedCondensedKKTSystem2D
+
+            if opt.kkt_system != "condensed":
+                raise ValueError("the P x Q distributed path factorises the condensed KKT system")
+            return HIPDistributedCondensedKKTSystem2D(be, st, nx, self.ind_ineq, self.qp.grid, self.H, self.A_I, self.A_J)
         extra = {}
         if opt.distributed:  # SURVEY.md 8e: one KKT system over the ranks of the default process group
             from . import dist as D
@@ -361,16 +369,22 @@ class MPCSolver:
         st.x.copy_(_push_interior(st.x, st.xl, st.xu, opt.bound_push, opt.bound_fac))
         be.fill(0.0, st.jacl)  # :144
         self.H, self.A, self.q = qp.H, qp.A, qp.q
+        spread = hasattr(qp, "grid")  # dist2d.DistributedQP: the matrices live on a P x Q grid of ranks
+        if spread:
+            self.A_I, self.A_J = qp.A_I, qp.A_J
         if opt.scaling and (self.m or nx):  # MadNLP.set_scaling!(..., 100) (:148-159)
             con_scale = torch.ones(self.m, dtype=torch.float64, device=dev)
             sparse = isinstance(qp.A, DeviceCSR)
             if self.m and nx:
-                rowmax = qp.A.row_absmax() if sparse else torch.linalg.vector_norm(qp.A, ord=float("inf"), dim=1)
+                rowmax = qp.row_absmax() if spread else (
+                    qp.A.row_absmax() if sparse else torch.linalg.vector_norm(qp.A, ord=float("inf"), dim=1))
                 con_scale = torch.minimum(one, 100.0 / rowmax)
             g = st.f[:nx]  # scratch: gradient at the pushed start
             g.copy_(qp.q)
             if qp.H is not None and nx:
-                if qp.H.dim() == 1:
+                if spread:
+                    g.add_(qp.hess_times(st.x[:nx]))
+                elif qp.H.dim() == 1:
                     g.add_(qp.H * st.x[:nx])
                 else:
                     be.gemv(0, nx, nx, 1.0, qp.H, nx, st.x, 1.0, g)
@@ -384,7 +398,12 @@ class MPCSolver:
                 st.x[nx:] *= cs
                 st.xl[nx:] *= cs
                 st.xu[nx:] *= cs
-                self.A = qp.A.scaled(con_scale) if sparse else (con_scale[:, None] * qp.A).contiguous()
+                if spread:
+                    self.A_I, self.A_J = qp.A_I.clone(), qp.A_J.clone()
+                    self.A_I[: self.m] *= con_scale[:, None]
+                    self.A_J[: self.m] *= con_scale[:, None]
+                else:
+                    self.A = qp.A.scaled(con_scale) if sparse else (con_scale[:, None] * qp.A).contiguous()
             if self.obj_scale != 1.0:
                 self.H = None if qp.H is None else (self.obj_scale * qp.H).contiguous()
                 self.q = self.obj_scale * qp.q

@@ -55,8 +55,9 @@ static int32_t dop_vsub(Dev*, double* a, const double* b, int64_t n) {
 }
 // C = beta C + alpha X Y' on the 128-tiles (ti, tj) with ti >= row0[tj]; the padded rows / columns that the HIP kernel
 // may READ (Mread, Nread) must be inside the buffers: touch them so that a wrong extent shows up under a sanitizer
-static int32_t dop_gemm(Dev*, double* C, int64_t ldc, const double* X, int64_t ldx, const double* Y, int64_t ldy, int64_t M,
-                        int64_t N, int64_t K, double alpha, double beta, int64_t Mread, int64_t Nread, const int64_t* row0) {
+static int32_t dop_gemm(Dev*, double* C, int64_t ldc, const double* Cin, int64_t ldcin, const double* X, int64_t ldx,
+                        const double* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, double alpha, double beta,
+                        int64_t Mread, int64_t Nread, const int64_t* row0) {
     volatile double sink = 0.0;
     if (K > 0 && Mread > 0) sink = X[(Mread - 1) + (K - 1) * ldx];
     if (K > 0 && Nread > 0) sink = Y[(Nread - 1) + (K - 1) * ldy];
@@ -66,7 +67,7 @@ static int32_t dop_gemm(Dev*, double* C, int64_t ldc, const double* X, int64_t l
         for (int64_t i = i0; i < M; ++i) {
             double s = 0.0;
             for (int64_t k = 0; k < K; ++k) s += X[i + k * ldx] * Y[j + k * ldy];
-            C[i + j * ldc] = (beta != 0.0 ? beta * C[i + j * ldc] : 0.0) + alpha * s;
+            C[i + j * ldc] = (beta != 0.0 && Cin ? beta * Cin[i + j * ldcin] : 0.0) + alpha * s;
         }
     }
     return 0;

@@ -1,0 +1,87 @@
+"""Rank program of tests/test_gpu_dist2d.py::test_kkt_*: ONE QP shared by P x Q ranks (madqp_dkkt_* above madqp_dist_*),
+all ranks on the one GPU of the test box, collectives host-staged over gloo.  Whole solves against the CPU oracle with
+the tolerance of tests/test_gpu_solver.py; every rank must produce bitwise the same trace."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import madqp_jl_amd as M  # noqa: E402
+from madqp_jl_amd.dist2d import DistCholesky2D, DistributedQP, HostStagedComm  # noqa: E402
+from oracle import mpc  # noqa: E402
+from oracle import qp as Q  # noqa: E402
+
+REG, OREG = M.FixedRegularization(1e-8, -1e-8), mpc.FixedRegularization(1e-8, -1e-8)
+
+
+def solve_case(be, grid, qp, synthetic_seed=None, **opts):
+    dq = DistributedQP.from_dense(be, grid, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
+    rec = {}
+    if synthetic_seed is not None:  # the generator's pieces are the slices of the full problem, bit for bit
+        ds = DistributedQP.synthetic(be, grid, synthetic_seed, qp.nvar, qp.ncon)
+        rec["pieces_equal"] = bool(torch.equal(ds.A_I, dq.A_I) and torch.equal(ds.A_J, dq.A_J) and torch.equal(ds.q, dq.q)
+                                   and torch.equal(ds.H[: grid.nloc, : grid.mloc], dq.H[: grid.nloc, : grid.mloc]))
+        dq = ds
+    s = M.MPCSolver(dq, be, regularization=REG, **opts)
+    r = s.solve()
+    resid = s.last_residual_ratio
+    s.close()
+    okw = {k: v for k, v in opts.items() if k in ("max_ncorr",)}
+    ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG, **okw)
+    keys = ("k", "alpha_p", "alpha_d", "inf_pr", "inf_du", "inf_compl", "mu")
+    rec.update(status=[r["status"], ref["status"]], iters=[r["iter"], ref["iter"]],
+               trace=[{k: float(t[k]) for k in keys} for t in r["trace"]],
+               ref_trace=[{k: float(t[k]) for k in keys} for t in ref["trace"]],
+               dx=float(np.max(np.abs(r["solution"] - ref["solution"]))),
+               dy=float(np.max(np.abs(r["multipliers"] - ref["multipliers"]))),
+               obj=[float(r["objective"]), float(ref["objective"])], resid=float(resid),
+               nfact=r["n_factorizations"], xsum=float(np.sum(r["solution"])).hex())
+    return rec
+
+
+def main():
+    out, Pg, Qg, nb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    world = Pg * Qg
+    comm = None
+    rank = 0
+    if world > 1:
+        dist.init_process_group("gloo")
+        rank = dist.get_rank()
+        comm = HostStagedComm(Pg, Qg)
+    be = M.HipBackend(0)
+    rec = {}
+    n, m = 900, 350
+    grid = DistCholesky2D(be, n, nb, (Pg, Qg), comm)
+    rec["qp_900_350"] = solve_case(be, grid, Q.synthetic_qp(20250614, n, m), synthetic_seed=20250614)
+    rec["qp_gondzio"] = solve_case(be, grid, Q.synthetic_qp(77, n, m), max_ncorr=3)
+    lp = Q.synthetic_qp(5, n, m, "lp")
+    rec["lp"] = solve_case(be, grid, lp)
+    eq = Q.synthetic_qp(9, n, m)
+    eq.lcon[[3, 10, 200]] = eq.ucon[[3, 10, 200]] = 0.25  # equality rows: Theta = 1e8
+    rec["qp_eq"] = solve_case(be, grid, eq)
+    rec["bytes_sent"] = grid.bytes_sent()
+    grid.close()
+    # a second shape: odd sizes, partial last tile, scaling != 1 (rows of A times 1000)
+    n2, m2 = 700, 130
+    grid2 = DistCholesky2D(be, n2, nb, (Pg, Qg), comm)
+    big = Q.synthetic_qp(31, n2, m2)
+    big.A[::3] *= 1000.0
+    big.lcon[::3] *= 1000.0
+    big.ucon[::3] *= 1000.0
+    rec["qp_scaled_rows"] = solve_case(be, grid2, big)
+    grid2.close()
+    if comm is not None:
+        assert comm.error is None, comm.error
+    json.dump(rec, open(f"{out}.{rank}", "w"))
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,3 +44,49 @@ def test_grid_on_one_gpu(tmp_path, P, Q, n, nb, port):
         assert (rec["p"], rec["q"]) == (k // Q, k % Q)
         assert rec["spd_info"] == 0 and rec["factor_err"] < 1e-11 and rec["solve_err"] < 1e-10, rec
         assert rec["pad_clean"] and rec["notpd_info"] == rec["notpd_expected"]
+
+
+def check_kkt_records(recs):
+    close = lambda a, b, tol: abs(a - b) <= tol * max(1.0, abs(a), abs(b))
+    for rec in recs:
+        assert rec["qp_900_350"]["pieces_equal"]
+        for name in ("qp_900_350", "qp_gondzio", "lp", "qp_eq", "qp_scaled_rows"):
+            c = rec[name]
+            assert c["status"] == [1, 1], (name, c["status"])
+            if name == "qp_eq":  # Theta = 1e8: the 2e-7 floor of the condensed form (test_kkt_system_conformance)
+                assert abs(c["iters"][0] - c["iters"][1]) <= 1 and c["dx"] <= 1e-5
+                continue
+            assert c["iters"][0] == c["iters"][1], (name, c["iters"])
+            for t, g in zip(c["trace"], c["ref_trace"]):
+                tol = 1e-9 if min(t["mu"], g["mu"]) >= 1e-4 else 1e-6
+                for key in ("alpha_p", "alpha_d", "inf_pr", "inf_du", "inf_compl", "mu"):
+                    assert close(t[key], g[key], tol), (name, t["k"], key, t[key], g[key])
+            assert c["dx"] <= 1e-7 and c["dy"] <= 1e-6 and close(c["obj"][0], c["obj"][1], 1e-9), (name, c["dx"], c["dy"])
+            assert c["resid"] < 1e-7
+    for name in ("qp_900_350", "qp_gondzio", "lp", "qp_eq", "qp_scaled_rows"):  # replicated state: bitwise equal ranks
+        assert all(rec[name]["trace"] == recs[0][name]["trace"] and rec[name]["xsum"] == recs[0][name]["xsum"]
+                   for rec in recs), name
+
+
+def test_kkt_single_rank(tmp_path):
+    """madqp_dkkt_* with a 1 x 1 grid (no collectives): the distributed KKT algebra against the oracle."""
+    out = str(tmp_path / "rec")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist2d_kkt_worker.py"), out, "1", "1", "256"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    check_kkt_records([json.load(open(f"{out}.0"))])
+
+
+@pytest.mark.parametrize("P,Q,nb,port", [(1, 2, 128, 29561), (2, 2, 256, 29563), (2, 1, 384, 29565)])
+def test_kkt_grid_on_one_gpu(tmp_path, P, Q, nb, port):
+    world = P * Q
+    out = str(tmp_path / "rec")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "dist2d_kkt_worker.py"), out, str(P), str(Q), str(nb)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    recs = [json.load(open(f"{out}.{k}")) for k in range(world)]
+    check_kkt_records(recs)
+    assert sum(rec["bytes_sent"] for rec in recs) > 0
