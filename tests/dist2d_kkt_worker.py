@@ -31,12 +31,18 @@ def solve_case(be, grid, qp, synthetic_seed=None, **opts):
     r = s.solve()
     resid = s.last_residual_ratio
     s.close()
+    s1 = M.MPCSolver(M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0),
+                     be, regularization=REG, **opts)  # the same problem through the one-GPU path
+    r1 = s1.solve()
+    s1.close()
     okw = {k: v for k, v in opts.items() if k in ("max_ncorr",)}
     ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG, **okw)
     keys = ("k", "alpha_p", "alpha_d", "inf_pr", "inf_du", "inf_compl", "mu")
     rec.update(status=[r["status"], ref["status"]], iters=[r["iter"], ref["iter"]],
                trace=[{k: float(t[k]) for k in keys} for t in r["trace"]],
                ref_trace=[{k: float(t[k]) for k in keys} for t in ref["trace"]],
+               single_trace=[{k: float(t[k]) for k in keys} for t in r1["trace"]],
+               dx_single=float(np.max(np.abs(r["solution"] - r1["solution"]))),
                dx=float(np.max(np.abs(r["solution"] - ref["solution"]))),
                dy=float(np.max(np.abs(r["multipliers"] - ref["multipliers"]))),
                obj=[float(r["objective"]), float(ref["objective"])], resid=float(resid),
@@ -66,13 +72,13 @@ def main():
     rec["qp_eq"] = solve_case(be, grid, eq)
     rec["bytes_sent"] = grid.bytes_sent()
     grid.close()
-    # a second shape: odd sizes, partial last tile, scaling != 1 (rows of A times 1000)
+    # a second shape: odd sizes, partial last tile, scaling != 1 (every third row of A times 40: row maxima ~180 > 100)
     n2, m2 = 700, 130
     grid2 = DistCholesky2D(be, n2, nb, (Pg, Qg), comm)
     big = Q.synthetic_qp(31, n2, m2)
-    big.A[::3] *= 1000.0
-    big.lcon[::3] *= 1000.0
-    big.ucon[::3] *= 1000.0
+    big.A[::3] *= 40.0
+    big.lcon[::3] *= 40.0
+    big.ucon[::3] *= 40.0
     rec["qp_scaled_rows"] = solve_case(be, grid2, big)
     grid2.close()
     if comm is not None:
