@@ -8,10 +8,11 @@ step lengths, iterate update, model evaluation) on a synthetic dense QP generate
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--nx 50000] [--m 20000]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards over independent QPs
-(BASELINE configs[3] style) -- every rank solves its own instance of the same size, no data-path
-collective, weak scaling; value = iterations of all ranks / max-over-ranks time.
-Rank 0 prints ONE JSON line.
+N > 1 (launched by torch.distributed.run, one rank per GPU): ONE QP of that size is shared by all GPUs on a P x Q
+grid -- 2-D block-cyclic distributed assembly, Cholesky and triangular solves over RCCL (csrc/dist.hip):
+strong scaling, value = iterations / max-over-ranks time.  The independent-QPs rate (every rank its own instance, no
+data-path collective: BASELINE configs[3] style weak scaling) is measured first and reported beside it
+(`independent_qps`); `--kkt local` makes it the headline.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -43,17 +44,18 @@ def parse():
     p.add_argument("--seed", type=int, default=20250614 + 1)
     p.add_argument("--driver", choices=("native", "python"), default="native",
                    help="host driver of the loop body: csrc/mpc.hip (one C call per iteration) or solver.py")
-    p.add_argument("--kkt", choices=("local", "distributed"), default="local",
-                   help="local: every GPU solves its own QP (weak scaling, the headline); distributed: all "
-                        "GPUs share ONE QP through the panel-cyclic distributed Cholesky (strong scaling)")
+    p.add_argument("--kkt", choices=("local", "distributed", "panels"), default=None,
+                   help="local: every GPU solves its own QP (weak scaling); distributed: all GPUs share ONE QP on a "
+                        "P x Q grid -- 2-D block-cyclic distributed Cholesky over RCCL (strong scaling); panels: round "
+                        "1's 1 x N layout.  Default: local on one GPU, distributed on several")
     p.add_argument("--kkt-system", choices=("condensed", "augmented"), default="condensed",
                    help="condensed (headline): K = H + Sigma_x + A' Theta A, Cholesky; augmented: the K2 form "
                         "[H + Sigma_x, A'; A, -D], L diag(I,-I) L' (reported with its own flop count)")
-    p.add_argument("--panel-width", type=int, default=None, help="block-column width of --kkt distributed")
-    p.add_argument("--no-distributed-extra", action="store_true",
-                   help="N > 1: skip the additional strong-scaling measurement of the distributed KKT path")
+    p.add_argument("--panel-width", type=int, default=None, help="tile size nb of --kkt distributed (panel width of --kkt panels)")
+    p.add_argument("--no-independent-leg", action="store_true",
+                   help="N > 1: skip the additional measurement of one independent QP per GPU")
     p.add_argument("--extra-timeout", type=float, default=240.0,
-                   help="N > 1: seconds after which the additional distributed-KKT measurement is given up")
+                   help="N > 1: seconds after which the shared-QP leg is given up (watchdog, exit code 3)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timers", action="store_true",
                    help="do not time the MFMA kernel classes with event pairs (roofline.achieved is then 0): the "
@@ -304,22 +306,33 @@ class StepLoop:
         self.steps += 1
 
 
-def measure(args, M, be, world, seed, distributed, max_ncorr=None, steps=None, warmup=None):
-    """Warm-up + the timed region (barrier / sync on both sides, MAX over ranks) for one solver set-up:
-    `distributed` False: this rank's own QP; True: all ranks share ONE QP."""
+def measure(args, M, be, world, seed, mode, max_ncorr=None, steps=None, warmup=None):
+    """Warm-up + the timed region (barrier / sync on both sides, MAX over ranks) for one solver set-up.
+    mode "local": this rank's own QP; "grid": ONE QP over all ranks on a P x Q grid (madqp_dist_* / madqp_dkkt_*,
+    SURVEY.md 8e); "panels": round 1's 1 x N panel-cyclic layout with replicated H, A and a gathered factor (dist.py)."""
     import torch
 
     nx, m = args.nx, args.m
     max_ncorr = args.max_ncorr if max_ncorr is None else max_ncorr
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
-    dq = M.DeviceQP.synthetic(be, seed, nx, m)
+    grid = None
+    if mode == "grid":
+        from madqp_jl_amd import dist2d
+
+        comm = None
+        if world > 1 and os.environ.get("MADQP_DIST_BACKEND", "nccl") != "nccl":
+            comm = dist2d.HostStagedComm(*dist2d.default_grid(world))  # rehearsal: several ranks on one GPU over gloo
+        grid = dist2d.DistCholesky2D(be, nx, args.panel_width, None, comm)
+        dq = dist2d.DistributedQP.synthetic(be, grid, seed, nx, m)
+    else:
+        dq = M.DeviceQP.synthetic(be, seed, nx, m)
     # options of scripts/benchmarks_cpu.jl:35-44 (kkt_system -> condensed, linear_solver -> HIP Cholesky)
     solver = M.MPCSolver(dq, be, max_iter=300, step_rule=M.AdaptiveStep(0.995),
                          regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12,
-                         max_ncorr=max_ncorr, scaling=True, distributed=distributed,
-                         panel_width=args.panel_width if distributed else None,
-                         driver="python" if distributed else args.driver, kkt_system=args.kkt_system)
+                         max_ncorr=max_ncorr, scaling=True, distributed=(mode == "panels"),
+                         panel_width=args.panel_width if mode == "panels" else None,
+                         driver=args.driver if mode == "local" else "python", kkt_system=args.kkt_system)
     solver.initialize()
     loop = StepLoop(solver, torch.cuda.synchronize)
     for _ in range(warmup):
@@ -338,18 +351,102 @@ def measure(args, M, be, world, seed, distributed, max_ncorr=None, steps=None, w
     elapsed = time.perf_counter() - t0 - loop.excluded
     prof = be.prof_get()
     be.prof_enable(())
-    res = dict(tmax=max_over_ranks(elapsed, world, be.device), prof=prof,
-               nfact=loop.factorizations(), reinits=loop.reinits, steps=steps, k=solver.k,
+    res = dict(tmax=max_over_ranks(elapsed, world, be.device), prof=prof, mode=mode, max_ncorr=max_ncorr,
+               nfact=loop.factorizations(), reinits=loop.reinits, steps=steps, warmup=warmup, k=solver.k,
                last_trace={k: solver.trace[-1][k] for k in ("k", "inf_pr", "inf_du", "inf_compl", "mu")}
                if solver.trace else None)
-    if distributed:
-        res["panel_width"] = solver.kkt.panel_width
-        res["panels"] = len(solver.kkt.dchol.panels)
-        res["bytes_broadcast_by_rank0"] = solver.kkt.dchol.bytes_sent
+    if mode == "panels":
+        res["layout"] = dict(kind="1 x N panel-cyclic, replicated H and A, gathered factor", panel_width=solver.kkt.panel_width,
+                             panels=len(solver.kkt.dchol.panels), bytes_broadcast_by_rank0=solver.kkt.dchol.bytes_sent)
+    if mode == "grid":
+        mem = 8 * (grid.ld * grid.ncp * (2 if dq.H is not None else 1) + dq.A_I.numel() + 2 * dq.A_J.numel())
+        res["layout"] = dict(kind="P x Q block-cyclic, nothing of order n^2 or m n replicated", grid=[grid.P, grid.Q],
+                             tile=grid.nb, local_matrix=[grid.mloc, grid.nloc],
+                             rank0_matrix_bytes=int(mem), bytes_broadcast_by_rank0=grid.bytes_sent())
     solver.close()
+    if grid is not None:
+        grid.close()
     del solver, dq
     torch.cuda.empty_cache()
     return res
+
+
+def bench_line(args, res, world):
+    """The JSON body of one measurement (rank 0)."""
+    nx, m = args.nx, args.m
+    tmax, prof, nfact, mode, steps = res["tmax"], res["prof"], res["nfact"], res["mode"], res["steps"]
+    shared = mode != "local"
+    # dominant kernel: gemm_tn_f64_kernel (assembly + panel updates + panel x inverse block)
+    gemm_ms = prof["syrk"][0] + prof["potrf_gemm"][0] + prof["potrf_trsm"][0]
+    gemm_launches = prof["syrk"][1] + prof["potrf_gemm"][1] + prof["potrf_trsm"][1]
+    alg_flops = nfact * (m * nx * nx + nx ** 3 / 3.0)  # SURVEY.md 8(d): SYRK m nx^2 + POTRF nx^3/3
+    if args.kkt_system == "augmented":  # no SYRK; L diag(I,-I) L' of order nx + m
+        alg_flops = nfact * (nx + m) ** 3 / 3.0
+    if shared:
+        alg_flops /= world  # rank 0's share of the MFMA work (cyclic deal of the tiles)
+    achieved = alg_flops / (gemm_ms * 1e-3) * 1e-12 if gemm_ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(nx, m)
+    if shared:
+        traffic, traffic_src = None, None
+    what = {"local": "one independent QP per GPU",
+            "grid": "ONE QP shared by all GPUs: 2-D block-cyclic distributed assembly + Cholesky + solves over RCCL "
+                    "(csrc/dist.hip)",
+            "panels": "ONE QP shared by all GPUs: 1 x N panel-cyclic Cholesky, replicated operands (dist.py)"}[mode]
+    par = "independent" if mode == "local" else (
+        "grid %dx%d nb=%d" % (*res["layout"]["grid"], res["layout"]["tile"]) if mode == "grid" else f"panels 1x{world}")
+    out = {
+        "metric": ("IPM iterations/sec (Mehrotra predictor-corrector, condensed KKT + Cholesky), dense QP fp64"
+                   if args.kkt_system == "condensed" else
+                   "IPM iterations/sec (Mehrotra predictor-corrector, augmented K2 KKT, L diag(I,-I) L'), dense QP fp64"),
+        "value": (steps / tmax) if shared else job_value(world, steps, tmax),
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": res["warmup"],
+        "ms_per_step": tmax / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if shared else "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"synthetic dense QP nx={nx} m={m} (0<=x<=1, 0<=Ax<=1, Wigner H, Gaussian A), "
+                               f"{what}, max_ncorr={res['max_ncorr']}",
+                   "nx": nx, "m": m, "n_slack": m, "max_ncorr": res["max_ncorr"], "parallelism": par,
+                   "driver": args.driver if mode == "local" else "python", "kkt": mode,
+                   "kkt_system": args.kkt_system,
+                   "options": f"max_ncorr={res['max_ncorr']}, FixedRegularization(1e-8,-1e-8), AdaptiveStep(0.995), "
+                              "mu_min=1e-12, max_iter=300 (scripts/benchmarks_cpu.jl:35-44, whose max_ncorr is 3) "
+                              "with kkt_system="
+                              + ("HIPAugmentedKKTSystem" if args.kkt_system == "augmented" else "HIPCondensedKKTSystem")
+                              + ", linear_solver=HIPCholeskySolver"},
+        # per factorisation (SURVEY.md 8d: linear_solver_time / #factorizations, #factorizations = iterations +
+        # start points + x100 retries); solve = the triangular sweeps of all solves that follow one factorisation
+        "kkt_factor_solve_ms": {
+            "assemble_syrk": prof["syrk"][0] / max(nfact, 1),
+            "factor_potrf": (prof["potrf_gemm"][0] + prof["potrf_trsm"][0] + prof["potrf_diag"][0]) / max(nfact, 1),
+            "solve_trsv": (prof["trsv"][0] / max(nfact, 1)) if prof["trsv"][1] else None,
+            "solves": prof["trsv"][1],
+            "factorizations": nfact,
+            "reinitializations_in_timed_region": res["reinits"],
+            "iteration_total": tmax / steps * 1e3,
+        },
+        "roofline": {
+            "bound": "mfma", "kernel": "gemm_tn_f64_kernel",
+            "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
+            "algorithmic_flops_per_launch": alg_flops / max(gemm_launches, 1),
+            "split": {k: {"ms": prof[k][0], "launches": prof[k][1]} for k in prof if prof[k][1]},
+        },
+        "iterations_done": res["k"],
+        "last_trace": res["last_trace"],
+    }
+    if shared:
+        out["distributed"] = res["layout"]
+        # whole-job rate against the chip peaks of all GPUs: what the scaling curve is judged by
+        out["roofline"]["job_fraction_of_peak"] = (
+            (nfact * (m * nx * nx + nx ** 3 / 3.0)) / tmax * 1e-12 / (PEAK_F64_MFMA_TFLOPS * world))
+    return out
 
 
 def main():
@@ -370,134 +467,83 @@ def main():
         print(json.dumps(cpu_full_size(args, M, be)), flush=True)
         be.close()
         return
-    shared = args.kkt == "distributed"
-    res = measure(args, M, be, world, args.seed if shared else rank_seed(args.seed, rank), shared)
-    tmax, prof, nfact = res["tmax"], res["prof"], res["nfact"]
+    mode = {"local": "local", "distributed": "grid", "panels": "panels", None: "local" if world == 1 else "grid"}[args.kkt]
+    if args.kkt_system != "condensed" and mode != "local":
+        mode = "local"  # the augmented system is factorised on one GPU
+    out = None
 
-    if rank == 0:
-        # dominant kernel: gemm_tn_f64_kernel (assembly + panel updates + panel x inverse block)
-        gemm_ms = prof["syrk"][0] + prof["potrf_gemm"][0] + prof["potrf_trsm"][0]
-        gemm_launches = prof["syrk"][1] + prof["potrf_gemm"][1] + prof["potrf_trsm"][1]
-        alg_flops = nfact * (m * nx * nx + nx ** 3 / 3.0)  # SYRK m nx^2 + POTRF nx^3/3
-        if args.kkt_system == "augmented":  # no SYRK; L diag(I,-I) L' of order nx + m
-            alg_flops = nfact * (nx + m) ** 3 / 3.0
-        if shared:
-            alg_flops /= world  # rank 0's share of the MFMA work (cyclic deal of the block columns)
-        achieved = alg_flops / (gemm_ms * 1e-3) * 1e-12 if gemm_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(nx, m)
-        if shared and world > 1:
-            traffic, traffic_src = None, None
-        what = ("ONE QP shared by all GPUs (panel-cyclic distributed assembly + Cholesky, madqp_jl_amd/dist.py)"
-                if shared else "one independent QP per GPU")
-        out = {
-            "metric": ("IPM iterations/sec (Mehrotra predictor-corrector, condensed KKT + Cholesky), dense QP fp64"
-                       if args.kkt_system == "condensed" else
-                       "IPM iterations/sec (Mehrotra predictor-corrector, augmented K2 KKT, L diag(I,-I) L'), dense QP fp64"),
-            "value": (args.steps / tmax) if shared else job_value(world, args.steps, tmax),
-            "unit": "iterations/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": tmax / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong" if shared else "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"synthetic dense QP nx={nx} m={m} (0<=x<=1, 0<=Ax<=1, Wigner H, Gaussian A), "
-                                   f"{what}, max_ncorr={args.max_ncorr}",
-                       "nx": nx, "m": m, "n_slack": m, "max_ncorr": args.max_ncorr,
-                       "driver": "python" if shared else args.driver, "kkt": args.kkt,
-                       "kkt_system": args.kkt_system,
-                       "options": f"max_ncorr={args.max_ncorr}, FixedRegularization(1e-8,-1e-8), AdaptiveStep(0.995), "
-                                  "mu_min=1e-12, max_iter=300 (scripts/benchmarks_cpu.jl:35-44, whose max_ncorr is 3) "
-                                  "with kkt_system="
-                                  + ("HIPAugmentedKKTSystem" if args.kkt_system == "augmented" else "HIPCondensedKKTSystem")
-                                  + ", linear_solver=HIPCholeskySolver"},
-            # per factorisation (linear_solver_time / #factorizations, #factorizations = iterations +
-            # start points + x100 retries); solve = the triangular sweeps of all solves that follow one factorisation
-            "kkt_factor_solve_ms": {
-                "assemble_syrk": prof["syrk"][0] / max(nfact, 1),
-                "factor_potrf": (prof["potrf_gemm"][0] + prof["potrf_trsm"][0] + prof["potrf_diag"][0]) / max(nfact, 1),
-                "solve_trsv": (prof["trsv"][0] / max(nfact, 1)) if prof["trsv"][1] else None,
-                "solves": prof["trsv"][1],
-                "factorizations": nfact,
-                "reinitializations_in_timed_region": res["reinits"],
-                "iteration_total": tmax / args.steps * 1e3,
-            },
-            "roofline": {
-                "bound": "mfma", "kernel": "gemm_tn_f64_kernel",
-                "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
-                "algorithmic_flops_per_launch": alg_flops / max(gemm_launches, 1),
-                "split": {k: {"ms": prof[k][0], "launches": prof[k][1]} for k in prof if prof[k][1]},
-            },
-            "iterations_done": res["k"],
-            "last_trace": res["last_trace"],
-        }
-        if shared:
-            out["distributed"] = {k: res[k] for k in ("panel_width", "panels", "bytes_broadcast_by_rank0")}
-    else:
-        out = None
-
-    if not args.no_second_ncorr and not shared:
+    def second_ncorr():
         # both max_ncorr settings are reported.  Same barrier / MAX-over-ranks protocol, fewer steps.
         other = 0 if args.max_ncorr else 3
         s2 = max(1, min(args.steps, 5))
-        r2 = measure(args, M, be, world, rank_seed(args.seed, rank), False, max_ncorr=other, steps=s2,
+        r2 = measure(args, M, be, world, rank_seed(args.seed, rank), "local", max_ncorr=other, steps=s2,
                      warmup=min(args.warmup, 1))
         if rank == 0:
             out[f"max_ncorr_{other}"] = {"value": job_value(world, s2, r2["tmax"]), "unit": "iterations/s",
                                          "ms_per_step": r2["tmax"] / s2 * 1e3, "steps": s2,
                                          "factorizations": r2["nfact"], "solves": r2["prof"]["trsv"][1]}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, nx, m)
 
-    if world > 1 and not shared and not args.no_distributed_extra:
-        # The same workload as ONE QP over all ranks (strong scaling of the distributed KKT path): reported beside
-        # the headline number, never instead of it -- the headline is complete at this point, and a watchdog prints
-        # it and ends the process should the extra leg not come back (a stuck collective raises nothing).
+    if world == 1 or mode == "local":
+        res = measure(args, M, be, world, args.seed if mode != "local" else rank_seed(args.seed, rank), mode)
+        if rank == 0:
+            out = bench_line(args, res, world)
+        if mode == "local" and not args.no_second_ncorr:
+            second_ncorr()
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, nx, m)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+    else:
+        # N > 1: the headline is ONE QP over all GPUs (strong scaling, north_star's 2-D block-cyclic distributed
+        # Cholesky).  The independent-QPs number (one QP per GPU, no collective in the data path) is measured first and
+        # reported beside it.  A collective that never returns raises nothing, so a watchdog guards the shared leg: it
+        # prints the line with what is complete (headline = the independent-QPs measurement, an `error` entry for the
+        # shared leg) and ends EVERY rank with exit code 3; nothing is retried in this process.
         import threading
 
+        weak = None
+        if not args.no_independent_leg:
+            weak = measure(args, M, be, world, rank_seed(args.seed, rank), "local", steps=max(1, min(args.steps, 5)),
+                           warmup=min(args.warmup, 1))
         state = {"printed": False}
         lock = threading.Lock()
 
-        def emit(extra_obj):
+        def emit(obj):
             with lock:
                 if state["printed"]:
                     return
                 state["printed"] = True
                 if rank == 0:
-                    out["distributed_kkt"] = extra_obj
-                    print(json.dumps(out), flush=True)
+                    print(json.dumps(obj), flush=True)
+
+        def fallback(msg):
+            if weak is None:
+                return {"error": msg, "n_gpus": world}
+            o = bench_line(args, weak, world) if rank == 0 else {}
+            o["distributed_kkt"] = {"error": msg}
+            return o
 
         def bail():
-            # a collective that never returns is a fault, not a result: the completed headline line is printed, then
-            # EVERY rank ends with exit code 3 (nothing is retried in this process)
-            emit({"error": f"no result after {args.extra_timeout} s; exit code 3"})
+            emit(fallback(f"the shared-QP leg gave no result after {args.extra_timeout} s; exit code 3"))
             os._exit(3)
 
         timer = threading.Timer(args.extra_timeout, bail)
         timer.daemon = True
         timer.start()
         try:
-            extra = measure(args, M, be, world, args.seed, True)
-            ep = extra["prof"]
-            extra_obj = {
-                "what": "the same workload as ONE QP over all GPUs (strong scaling; madqp_jl_amd/dist.py)",
-                "value": args.steps / extra["tmax"], "unit": "iterations/s",
-                "ms_per_step": extra["tmax"] / args.steps * 1e3, "scaling": "strong",
-                "panel_width": extra["panel_width"], "panels": extra["panels"],
-                "bytes_broadcast_by_rank0": extra["bytes_broadcast_by_rank0"],
-                "rank0_ms": {k: ep[k][0] / max(extra["nfact"], 1) for k in ep if ep[k][1]},
-            }
-        except Exception as e:  # keep the headline line even if the extra leg fails
-            extra_obj = {"error": f"{type(e).__name__}: {e}"[:300]}
+            res = measure(args, M, be, world, args.seed, mode)
+        except Exception as e:
+            timer.cancel()
+            emit(fallback(f"{type(e).__name__}: {e}"[:400] + "; exit code 3"))
+            os._exit(3)
         timer.cancel()
-        emit(extra_obj)
-    elif rank == 0:
-        print(json.dumps(out), flush=True)
+        if rank == 0:
+            out = bench_line(args, res, world)
+            if weak is not None:
+                out["independent_qps"] = {"what": "one independent QP per GPU, no collective in the data path (weak scaling)",
+                                          "value": job_value(world, weak["steps"], weak["tmax"]), "unit": "iterations/s",
+                                          "ms_per_step": weak["tmax"] / weak["steps"] * 1e3, "steps": weak["steps"]}
+        emit(out)
 
     be.close()
     if world > 1:

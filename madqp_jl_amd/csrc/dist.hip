@@ -7,7 +7,7 @@
 // / ncclAllReduce on the world communicator and on row / column communicators made with ncclCommSplit), resolved at
 // run time from the RCCL the process already has (torch's) -- or, when the caller hands in `madqp_comm_ops`, its
 // host-staged callbacks (multi-rank rehearsals on one GPU over gloo, where RCCL refuses two ranks per device).
-// The panel phase of step k+1 runs on its own stream beside the trailing update of step k.
+// The collectives of step k+1 run on their own stream beside the trailing update of step k (dist_core.inc).
 #include <dlfcn.h>
 
 #include <rccl/rccl.h>
@@ -243,7 +243,7 @@ int32_t dop_tile_solve(Dev* dev, int32_t trans, const double* L, int64_t ld, con
     return madqp_trsv_tile(dev->ctx, trans, L, ld, W, v, w, scratch, dev->ctl);
 }
 
-// ---- streams: 0 begin (panel stream), 1 panel -> update, 2 update -> panel, 3 back to update, 4 join
+// ---- streams (dist_core.inc): kernels on sU, collectives on sP.  0 begin, 1 U -> P, 2 P -> U, 3 back to U without waiting, 4 join
 int32_t dop_phase(Dev* dev, int code) {
     madqp_ctx* ctx = dev->ctx;
     if (!dev->two_streams) return 0;
@@ -252,17 +252,17 @@ int32_t dop_phase(Dev* dev, int code) {
             HIP_TRY(ctx, hipEventRecord(dev->ev[0], dev->main));
             HIP_TRY(ctx, hipStreamWaitEvent(dev->sP, dev->ev[0], 0));
             HIP_TRY(ctx, hipStreamWaitEvent(dev->sU, dev->ev[0], 0));
-            ctx->stream = dev->sP;
-            break;
-        case 1:
-            HIP_TRY(ctx, hipEventRecord(dev->ev[1], dev->sP));
-            HIP_TRY(ctx, hipStreamWaitEvent(dev->sU, dev->ev[1], 0));
             ctx->stream = dev->sU;
             break;
-        case 2:
-            HIP_TRY(ctx, hipEventRecord(dev->ev[2], dev->sU));
-            HIP_TRY(ctx, hipStreamWaitEvent(dev->sP, dev->ev[2], 0));
+        case 1:
+            HIP_TRY(ctx, hipEventRecord(dev->ev[1], dev->sU));
+            HIP_TRY(ctx, hipStreamWaitEvent(dev->sP, dev->ev[1], 0));
             ctx->stream = dev->sP;
+            break;
+        case 2:
+            HIP_TRY(ctx, hipEventRecord(dev->ev[2], dev->sP));
+            HIP_TRY(ctx, hipStreamWaitEvent(dev->sU, dev->ev[2], 0));
+            ctx->stream = dev->sU;
             break;
         case 3:
             ctx->stream = dev->sU;
@@ -372,7 +372,19 @@ extern "C" int32_t madqp_dist_create(madqp_ctx* ctx, int32_t rank, int32_t world
         dev_destroy(dev);
         return r == MADQP_ERR_ARG ? madqp_fail(ctx, r, "madqp_dist_create: bad grid / tile size") : r;
     }
-    if (world > 1 && !ops) {  // RCCL: world communicator, then one communicator per process row and per process column
+    // MADQP_DIST_FORCE_RCCL=1: build the communicators and run every collective through RCCL even with one rank (a
+    // one-GPU box can then exercise the RCCL calls themselves; the id is drawn here when the caller gave none)
+    static const int force = getenv("MADQP_DIST_FORCE_RCCL") ? atoi(getenv("MADQP_DIST_FORCE_RCCL")) : 0;
+    ncclUniqueId own_id;
+    if (world == 1 && !ops && force) {
+        if (!rccl().ok || rccl().GetUniqueId(&own_id) != ncclSuccess) {
+            madqp_dist_destroy(d);
+            return madqp_fail(ctx, MADQP_ERR_STATE, "MADQP_DIST_FORCE_RCCL: RCCL is not available in this process");
+        }
+        nccl_id128 = &own_id;
+        d->force_comm = 1;
+    }
+    if ((world > 1 || d->force_comm) && !ops) {  // RCCL: world communicator, then one per process row / column
         if (!rccl().ok) {
             madqp_dist_destroy(d);
             return madqp_fail(ctx, MADQP_ERR_STATE, "RCCL is not available in this process (librccl.so)");

@@ -96,3 +96,15 @@ def test_kkt_grid_on_one_gpu(tmp_path, P, Q, nb, port):
     recs = [json.load(open(f"{out}.{k}")) for k in range(world)]
     check_kkt_records(recs)
     assert sum(rec["bytes_sent"] for rec in recs) > 0
+
+
+def test_rccl_calls_with_one_rank(tmp_path):
+    """The RCCL side of dist.hip -- run-time binding to the process's librccl, ncclCommInitRank, two ncclCommSplit,
+    every ncclBroadcast / ncclReduce / ncclAllReduce of the schedule on the internal streams -- cannot meet a second
+    rank on a one-GPU box; MADQP_DIST_FORCE_RCCL=1 makes a single rank go through all of it (groups of one)."""
+    out = str(tmp_path / "rec")
+    env = dict(os.environ, MADQP_DIST_FORCE_RCCL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist2d_kkt_worker.py"), out, "1", "1", "256"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    check_kkt_records([json.load(open(f"{out}.0"))])
