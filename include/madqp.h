@@ -451,10 +451,11 @@ int32_t madqp_mpc_body(madqp_mpc* mpc, madqp_mpc_info* info_host);
 /* B problems with the same (nx, m) and the same bound / inequality pattern advance in lock step:
  * assembly and Cholesky are batched launches of the MFMA kernels, the rest of an iteration is one
  * workgroup per problem; scalars stay on the device, a finished problem is masked out by its status
- * word (csrc/batch.hip).  Options: madqp_mpc_options with step_rule 0/1 and max_ncorr 0; a failed
- * factorisation ends that problem (no x100 retry) -- re-solve it with the per-problem driver. */
+ * word (csrc/batch.hip).  Options: every step rule and regularization of madqp_mpc_options, Gondzio corrections;
+ * a failed factorisation is retried per problem with del_w, del_c x 100, three trials in all
+ * (src/linear_solver.jl:6-17); a problem still not factorised then ends with status -3. */
 #define MADQP_BATCH_SCALARS 16 /* per problem: mu, alpha_p, alpha_d, obj, inf_pr, inf_du, inf_compl, dnorm,
-                                  norm_b, norm_c, del_w, del_c, residual_ratio, reg state (2), spare */
+                                  norm_b, norm_c, del_w, del_c, residual_ratio, reg state (2), number of factorisations */
 typedef struct madqp_batch madqp_batch;
 typedef struct madqp_batch_data { /* caller-owned device arrays, problem b at offset b * length; borrowed */
     const double* H;   /* [B][nx][nx] symmetric, or NULL for LPs */

@@ -55,7 +55,7 @@ class CBatchData(C.Structure):
 
 
 BATCH_SCALARS = ("mu", "alpha_p", "alpha_d", "obj", "inf_pr", "inf_du", "inf_compl", "dnorm", "norm_b", "norm_c",
-                 "del_w", "del_c", "residual_ratio", "reg_p", "reg_d", "spare")
+                 "del_w", "del_c", "residual_ratio", "reg_p", "reg_d", "n_factorizations")
 
 
 class CMpcInfo(C.Structure):

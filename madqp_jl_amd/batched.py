@@ -155,7 +155,8 @@ class BatchedMPCSolver:
                 solution=x[b, :self.nx].copy(), multipliers=y[b] * cs[b] / os_[b],
                 multipliers_L=zl[b, :self.nx] / os_[b], multipliers_U=zu[b, :self.nx] / os_[b],
                 inf_pr=scal[b, col["inf_pr"]], inf_du=scal[b, col["inf_du"]],
-                inf_compl=scal[b, col["inf_compl"]], mu=scal[b, col["mu"]]))
+                inf_compl=scal[b, col["inf_compl"]], mu=scal[b, col["mu"]], del_w=scal[b, col["del_w"]],
+                n_factorizations=int(scal[b, col["n_factorizations"]])))
         return out
 
     def close(self):

@@ -15,8 +15,9 @@
 //
 // Same arithmetic as the single-problem path (src/solver.jl:127-182, 254-345 in the same order);
 // sums are accumulated in a different order, so results agree to rounding, not bitwise.  All step
-// rules and Gondzio's corrections are in; not covered here (use the per-problem driver): the x100
-// regularization retry (a failed factorisation ends that problem with status -3), normal equations.
+// rules, Gondzio's corrections and the x100 regularization retry of src/linear_solver.jl:6-17 (two extra, masked
+// assembly + Cholesky rounds per iteration that only the problems whose factorisation failed take part in) are in;
+// not covered here (use the per-problem driver): the normal-equations form.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -32,7 +33,7 @@ constexpr int64_t WBLK = 2 * NB * NB;
 
 enum {
     S_MU = 0, S_ALPHA_P, S_ALPHA_D, S_OBJ, S_INF_PR, S_INF_DU, S_INF_COMPL, S_DNORM, S_NORM_B, S_NORM_C,
-    S_DEL_W, S_DEL_C, S_RATIO, S_REG_P, S_REG_D, S_SPARE, S_COUNT
+    S_DEL_W, S_DEL_C, S_RATIO, S_REG_P, S_REG_D, S_NFACT, S_COUNT
 };
 static_assert(S_COUNT == MADQP_BATCH_SCALARS, "scalar block layout is part of the ABI");
 
@@ -47,7 +48,7 @@ struct BQ {  // device view of the batch (by value in the kernel arguments); pro
     double *l_diag, *l_lower, *u_diag, *u_lower, *corr_lb, *corr_ub;
     double *theta, *t, *u, *K, *S, *winv, *tmp;
     double* scal;
-    int32_t *status, *iters, *info;
+    int32_t *status, *iters, *info, *retry_skip;
     madqp_mpc_options opt;
     double mu_init, bound_fac;
 };
@@ -138,7 +139,7 @@ struct madqp_batch {
     BQ q;
     std::vector<void*> owned;
     int32_t* d_active;
-    // one lock-step iteration (13 launches) captured once as a hipGraph and replayed on an internal stream
+    // one lock-step iteration (13 launches + 2 masked retry rounds) captured once as a hipGraph and replayed on an internal stream
     hipStream_t sG = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -165,7 +166,7 @@ int32_t dalloc(madqp_batch* b, T** p, int64_t count, bool zero = false) {
 }
 
 // build_kkt! + factorize! for every active problem: one assembly launch, ~2 nx/128 launches of Cholesky
-int32_t factor_all(madqp_batch* b) {
+int32_t factor_all(madqp_batch* b, const int32_t* skip) {
     madqp_ctx* ctx = b->ctx;
     const BQ& q = b->q;
     if (q.nx == 0) return hipMemsetAsync(q.info, 0, q.B * sizeof(int32_t), ctx->stream) == hipSuccess
@@ -193,11 +194,10 @@ int32_t factor_all(madqp_batch* b) {
         g.X = g.Y = q.K;
         g.Mread = g.Nread = 0;
     }
-    GemmBatch bt{q.B, q.kpad * q.npad, q.kpad * q.npad, q.ldk * q.ldk, q.nx * q.nx, q.n, q.status};
+    GemmBatch bt{q.B, q.kpad * q.npad, q.kpad * q.npad, q.ldk * q.ldk, q.nx * q.nx, q.n, skip};
     int32_t r = madqp_gemm_tn(ctx, g, MADQP_PROF_SYRK, nullptr, 0, &bt);
     if (r) return r;
-    return madqp_chol_factor_batched(ctx, q.K, q.ldk, q.nx, q.ldk * q.ldk, q.winv, q.nblk * WBLK, q.info, q.B,
-                                     q.status);
+    return madqp_chol_factor_batched(ctx, q.K, q.ldk, q.nx, q.ldk * q.ldk, q.winv, q.nblk * WBLK, q.info, q.B, skip);
 }
 }  // namespace
 
@@ -305,6 +305,7 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
     BALLOC(q.status, B, true);
     BALLOC(q.iters, B, true);
     BALLOC(q.info, B, true);
+    BALLOC(q.retry_skip, B, true);
     BALLOC(b->d_active, 1, true);
 #undef BALLOC
     if (r == MADQP_OK && ns &&
@@ -336,7 +337,7 @@ extern "C" int32_t madqp_batch_init(madqp_batch* b, double mu_init, double bound
             hipLaunchKernelGGL(wg256::bq_init_pre_kernel, dim3((unsigned)b->q.B), dim3(256), 0, ctx->stream, b->q);
         LAUNCH_CHECK(ctx);
     }
-    int32_t r = factor_all(b);
+    int32_t r = factor_all(b, b->q.status);
     if (r) return r;
     ProfScope ps(ctx, MADQP_PROF_VEC);
     if (b->wide)
@@ -359,8 +360,19 @@ static int32_t launch_iteration(madqp_batch* b) {
             hipLaunchKernelGGL(wg256::bq_iter_pre_kernel, dim3((unsigned)q.B), dim3(256), 0, ctx->stream, q);
         LAUNCH_CHECK(ctx);
     }
-    int32_t r = factor_all(b);
+    int32_t r = factor_all(b, q.status);
     if (r) return r;
+    for (int trial = 1; trial < 3; ++trial) {  // src/linear_solver.jl:7: three trials in all
+        {
+            ProfScope ps(ctx, MADQP_PROF_VEC);
+            if (b->wide)
+                hipLaunchKernelGGL(wg512::bq_retry_kernel, dim3((unsigned)q.B), dim3(512), 0, ctx->stream, q);
+            else
+                hipLaunchKernelGGL(wg256::bq_retry_kernel, dim3((unsigned)q.B), dim3(256), 0, ctx->stream, q);
+            LAUNCH_CHECK(ctx);
+        }
+        if ((r = factor_all(b, q.retry_skip))) return r;
+    }
     ProfScope ps(ctx, MADQP_PROF_VEC);
     const bool gz = q.opt.max_ncorr > 0;
     if (b->wide && gz)

@@ -246,37 +246,46 @@ class MPCSolver:
             raise TypeError(rule)
 
     def _mehrotra_adaptive_step(self, rule):  # kernels.jl:325-374
+        """The reference reads ~20 single elements at the blocking indices (`CUDA.@allowscalar`, :349-369).  Here the
+        (at most four) blocking rows are gathered on the device and cross the bus in ONE read-back."""
         st = self.st
         gamma_a = 1.0 / (1.0 - rule.gamma_f)
         (axl, axu, azl, azu), (i_xl, i_xu, i_zl, i_zu) = self.be.get_alpha_max(st, 1.0)
         max_ap, max_ad = min(axl, axu), min(azl, azu)
         mu_full = self.be.get_affine_complementarity_measure(st, max_ap, max_ad) / gamma_a
         dx, dzl, dzu = st.primal(st.d), st.dual_lb(st.d), st.dual_ub(st.d)
-
-        def at(vec, ind, i):  # scalar element reads at the blocking index (:351-368)
-            return float(vec[int(ind[i])]) if ind is not None else float(vec[i])
-
+        # one row per blocking index: (x, bound, z, dx, dz) at that index
+        picks = []  # (key, list index i, lower?)
+        if max_ap < 1.0:
+            picks.append(("p", i_xl, True) if axl <= axu else ("p", i_xu, False))
+        if max_ad < 1.0:
+            picks.append(("d", i_zl, True) if azl <= azu else ("d", i_zu, False))
+        vals = {}
+        if picks:
+            rows = []
+            for _, i, lower in picks:
+                j = (st.ind_lb if lower else st.ind_ub)[i]
+                rows.append(torch.stack([st.x[j], (st.xl if lower else st.xu)[j], (st.zl if lower else st.zu)[j], dx[j],
+                                         (dzl if lower else dzu)[i]]))
+            host = torch.stack(rows).cpu().numpy()  # the single device-to-host copy
+            vals = {k: host[r] for r, (k, _, _) in enumerate(picks)}
         alpha_p = alpha_d = 1.0
         if max_ap < 1.0:
+            x, bnd, z, dxi, dzi = vals["p"]
             if axl <= axu:
-                i = i_xl
-                tmp = mu_full / (at(st.zl, st.ind_lb, i) + max_ad * at(dzl, None, i))
-                alpha_p = (at(st.x, st.ind_lb, i) - at(st.xl, st.ind_lb, i) - tmp) / (-at(dx, st.ind_lb, i))
+                tmp = mu_full / (z + max_ad * dzi)
+                alpha_p = (x - bnd - tmp) / (-dxi)
             else:
-                i = i_xu
-                tmp = mu_full / (at(st.zu, st.ind_ub, i) + max_ad * at(dzu, None, i))
-                alpha_p = (at(st.xu, st.ind_ub, i) - at(st.x, st.ind_ub, i) - tmp) / at(dx, st.ind_ub, i)
+                tmp = mu_full / (z + max_ad * dzi)
+                alpha_p = (bnd - x - tmp) / dxi
         if max_ad < 1.0:
+            x, bnd, z, dxi, dzi = vals["d"]
             if azl <= azu:
-                i = i_zl
-                tmp = mu_full / (at(st.x, st.ind_lb, i) + max_ap * at(dx, st.ind_lb, i)
-                                 - at(st.xl, st.ind_lb, i))
-                alpha_d = -(at(st.zl, st.ind_lb, i) - tmp) / at(dzl, None, i)
+                tmp = mu_full / (x + max_ap * dxi - bnd)
+                alpha_d = -(z - tmp) / dzi
             else:
-                i = i_zu
-                tmp = mu_full / (at(st.xu, st.ind_ub, i) - at(st.x, st.ind_ub, i)
-                                 - max_ap * at(dx, st.ind_ub, i))
-                alpha_d = -(at(st.zu, st.ind_ub, i) - tmp) / at(dzu, None, i)
+                tmp = mu_full / (bnd - x - max_ap * dxi)
+                alpha_d = -(z - tmp) / dzi
         self.alpha_p = max(alpha_p, rule.gamma_f * max_ap)
         self.alpha_d = max(alpha_d, rule.gamma_f * max_ad)
 

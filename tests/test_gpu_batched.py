@@ -120,3 +120,33 @@ def test_batched_rejects_mixed_patterns(hip):
         M.BatchedMPCSolver([to_device(a, hip), to_device(b, hip)], hip, regularization=REG)
     with pytest.raises(ValueError):
         M.BatchedMPCSolver([to_device(a, hip)], hip, regularization=REG, kkt_system="normal")
+
+
+def test_batched_regularization_retry(hip):
+    """src/linear_solver.jl:6-17 inside the lock-step engine: one problem of the batch has a slightly indefinite
+    Hessian entry on a free variable, so its factorisation fails at delta_w = 1e-8 and succeeds after the x100 retry;
+    it must follow the oracle's retry count (n_factorizations) and iterates while the other problems -- which sit the
+    masked retry rounds out -- follow theirs.  The free variable is free in EVERY problem (one bound pattern per
+    batch); only problem 2 has the negative curvature."""
+    qps, free, bad = [], 3, 2
+    for i in range(5):
+        qp = Q.synthetic_qp(40 + i, 20, 8)
+        qp.lvar[free], qp.uvar[free] = -np.inf, np.inf
+        qp.H = np.diag(np.diag(qp.H))
+        qp.A[:, free] = 0.0
+        qp.q[free] = 0.0
+        if i == bad:
+            qp.H[free, free] = -1e-7
+        qps.append(qp)
+    s = M.BatchedMPCSolver([to_device(q, hip) for q in qps], hip, regularization=REG, max_iter=4)
+    res = s.solve()
+    s.close()
+    for i, (qp, r) in enumerate(zip(qps, res)):
+        ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG, max_iter=4)
+        assert r["status"] == ref["status"] and r["iter"] == ref["iter"], (i, r["status"], ref["status"], r["iter"], ref["iter"])
+        assert r["n_factorizations"] == ref["n_factorizations"], (i, r["n_factorizations"], ref["n_factorizations"])
+        t = ref["trace"][-1]
+        assert close(r["inf_pr"], t["inf_pr"], 1e-6) and close(r["inf_du"], t["inf_du"], 1e-6), i
+        assert close(r["mu"], t["mu"], 1e-6) and close(r["del_w"], t["del_w"], 1e-12), i
+        assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-6, i
+    assert res[bad]["n_factorizations"] > res[0]["n_factorizations"]  # only the bad problem paid for retries
