@@ -75,6 +75,12 @@ int32_t solve_system(madqp_mpc* s) {
     TRY(madqp_kkt_solve(s->kkt, &s->st, s->st.d));
     TRY(madqp_copy(s->ctx, len, s->st.p, s->w1));
     TRY(madqp_kkt_mul(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));
+    for (int32_t it = 0; it < s->opt.refine_steps; ++it) {  // extension (off by default): d += K^-1 (p - K d)
+        TRY(madqp_kkt_solve(s->kkt, &s->st, s->w1));
+        TRY(madqp_axpy(s->ctx, len, 1.0, s->w1, s->st.d));
+        TRY(madqp_copy(s->ctx, len, s->st.p, s->w1));
+        TRY(madqp_kkt_mul(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));
+    }
     double nrm[3];
     TRY(madqp_norm_inf3(s->ctx, len, s->w1, s->st.p, s->st.d, nrm));
     const double ratio = nrm[0] / std::max(1.0, nrm[1]);

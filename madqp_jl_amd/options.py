@@ -53,6 +53,11 @@ class IPMOptions:
         distributed=False,  # True: assembly + Cholesky shared by the ranks of torch.distributed (dist.py)
         panel_width=None,  # block-column width of the distributed factorisation (multiple of 128)
         driver="python",  # "python": this package drives each kernel; "native": one C call per iteration
+        # extension (0 = the reference's solve_system!, src/linear_solver.jl:19-45): steps of iterative refinement with the
+        # residual that solve_system! forms anyway.  The explicit 128 x 128 block inverses of the device factorisation
+        # cost a little backward stability against LAPACK's substitutions on problems at the edge of fp64 (LPs through
+        # the condensed form); one step more than makes up for it (+1 solve and +1 mul! per solve)
+        refine_steps=0,
     )
 
     def __init__(self, **kw):

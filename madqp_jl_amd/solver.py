@@ -66,7 +66,8 @@ def native_options(opt) -> CMpcOptions:
     """``madqp_mpc_options`` (include/madqp.h) of an :class:`IPMOptions`."""
     rule, reg = opt.step_rule, opt.regularization
     c = CMpcOptions(tol=opt.tol, max_iter=opt.max_iter, max_ncorr=opt.max_ncorr, mu_min=opt.mu_min,
-                    check_residual=int(bool(opt.check_residual)), tol_linear_solve=opt.tol_linear_solve)
+                    check_residual=int(bool(opt.check_residual)), tol_linear_solve=opt.tol_linear_solve,
+                    refine_steps=int(opt.refine_steps))
     if isinstance(rule, ConservativeStep):
         c.step_rule, c.step_param = 0, rule.tau
     elif isinstance(rule, AdaptiveStep):
@@ -215,6 +216,11 @@ class MPCSolver:
         self.kkt.solve(st.d)
         be.copy(st.p, st.w1)
         self.kkt.mul(st.w1, st.d, -1.0, 1.0)
+        for _ in range(self.opt.refine_steps):  # extension, off by default: d += K^-1 (p - K d)
+            self.kkt.solve(st.w1)
+            be.axpy(1.0, st.w1, st.d)
+            be.copy(st.p, st.w1)
+            self.kkt.mul(st.w1, st.d, -1.0, 1.0)
         norm_w, norm_p, norm_d = be.norm_inf3(st.w1, st.p, st.d)
         ratio = norm_w / max(1.0, norm_p)
         self.last_residual_ratio = ratio

@@ -102,3 +102,23 @@ def test_soak(hip, seed0, count, only_lp, drivers):
     print(f"soak seed0={seed0}: {cases} solves, {len(ties)} threshold ties: {ties}")
     assert all(lp for (_, _, _, lp, _), _, _ in ties), ("a threshold tie on a QP", ties)
     assert len(ties) <= max(2, cases // 20), ties  # a few per cent of the LPs at most
+
+
+@pytest.mark.parametrize("driver", ["python", "native"])
+def test_refinement_step_on_the_edge_of_fp64(hip, driver):
+    """`refine_steps=1` (extension, off by default): one step of iterative refinement with the residual that
+    solve_system! forms anyway.  On seed 9195 -- the LP where the explicit block inverses cost the device path an
+    iteration against the oracle on the GPU box's host -- the refined solves leave a smaller residual and the solver
+    needs no more iterations than the oracle on any host (12 or 13)."""
+    qp = Q.random_qp(9195, 186, 78, True)
+    ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG)
+    dq = M.DeviceQP.from_numpy(hip.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
+    out = {}
+    for steps in (0, 1):
+        s = M.MPCSolver(dq, hip, regularization=REG, driver=driver, refine_steps=steps)
+        out[steps] = s.solve()
+        out[steps]["resid"] = s.last_residual_ratio
+        s.close()
+    assert out[0]["status"] == out[1]["status"] == M.SOLVE_SUCCEEDED
+    assert out[1]["iter"] <= min(out[0]["iter"], ref["iter"])
+    assert abs(out[1]["objective"] - ref["objective"]) <= 1e-7 * max(1.0, abs(ref["objective"]))

@@ -252,3 +252,13 @@ def test_augmented_kkt_options():
         run(qp, kkt_system="augmented", distributed=True)
     with pytest.raises(ValueError):
         run(qp, kkt_system="no-such-system")
+
+
+def test_refine_steps_reduce_the_residual():
+    """refine_steps (extension, default 0): d += K^-1 (p - K d) in solve_system, through the fake backend."""
+    qp = Q.synthetic_qp(20250615, 30, 12, "lp")
+    s0, r0 = run(qp)
+    s1, r1 = run(qp, refine_steps=2)
+    assert r0["status"] == r1["status"] == M.SOLVE_SUCCEEDED and abs(r0["iter"] - r1["iter"]) <= 1
+    assert abs(r0["objective"] - r1["objective"]) <= 1e-8
+    assert s1.last_residual_ratio <= 10 * s0.last_residual_ratio + 1e-14
