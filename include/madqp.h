@@ -429,7 +429,8 @@ typedef struct madqp_mpc_options { /* src/utils.jl:69-103 */
     double tol_linear_solve;
     int32_t refine_steps;   /* extension, default 0 = the reference's solve_system!: steps of iterative refinement
                                d += K^-1 (p - K d) with the residual src/linear_solver.jl:29-31 already forms */
-    int32_t reserved_;
+    int32_t kkt_form;       /* madqp_batch_* only: 0 condensed K = H + Sigma_x + A' Theta A, 1 the reference's normal
+                               equations A Sigma^-1 A' (NormalKKTSystem, LP only) */
 } madqp_mpc_options;
 typedef struct madqp_mpc_info { /* print_iter tuple (src/structure.jl:178-195) + counters */
     int64_t k;

@@ -45,7 +45,7 @@ class CMpcOptions(C.Structure):
     _fields_ = [("tol", f64), ("max_iter", i64), ("max_ncorr", i32), ("step_rule", i32),
                 ("step_param", f64), ("regularization", i32), ("check_residual", i32),
                 ("delta_p", f64), ("delta_d", f64), ("delta_min", f64), ("mu_min", f64),
-                ("tol_linear_solve", f64), ("refine_steps", i32), ("reserved_", i32)]
+                ("tol_linear_solve", f64), ("refine_steps", i32), ("kkt_form", i32)]
 
 
 class CBatchData(C.Structure):

@@ -27,8 +27,9 @@ class BatchedMPCSolver:
             raise ValueError("empty batch")
         self.be, self.qps = backend, list(qps)
         self.opt = IPMOptions(**opts)
-        if self.opt.kkt_system != "condensed" or self.opt.distributed or self.opt.check_residual:
-            raise ValueError("the batched driver supports the condensed KKT system on one GPU")
+        if self.opt.kkt_system not in ("condensed", "normal") or self.opt.distributed or self.opt.check_residual:
+            raise ValueError("the batched driver supports the condensed KKT system and the normal equations, on one GPU")
+        self.normal = self.opt.kkt_system == "normal"
         q0 = self.qps[0]
         self.B, self.nx, self.m = len(self.qps), q0.nvar, q0.ncon
         dev = backend.device
@@ -53,7 +54,10 @@ class BatchedMPCSolver:
         self.nlb, self.nub = self.ind_lb.numel(), self.ind_ub.numel()
         reg = self.opt.regularization
         self._copt = native_options(self.opt)
-        if len(self.ind_eq) and not (self._copt.regularization != 0 and reg.delta_d < 0.0):
+        self._copt.kkt_form = 1 if self.normal else 0
+        if self.normal and q0.H is not None:
+            raise ValueError("The KKT system NormalKKTSystem supports only linear programs.")  # normalkkt.jl:45-48
+        if not self.normal and len(self.ind_eq) and not (self._copt.regularization != 0 and reg.delta_d < 0.0):
             raise ValueError("the condensed KKT system needs dual regularization delta_d < 0 "
                              "when the problem has equality constraints")
         self.H = None if q0.H is None else st("H")

@@ -16,8 +16,8 @@
 // Same arithmetic as the single-problem path (src/solver.jl:127-182, 254-345 in the same order);
 // sums are accumulated in a different order, so results agree to rounding, not bitwise.  All step
 // rules, Gondzio's corrections and the x100 regularization retry of src/linear_solver.jl:6-17 (two extra, masked
-// assembly + Cholesky rounds per iteration that only the problems whose factorisation failed take part in) are in;
-// not covered here (use the per-problem driver): the normal-equations form.
+// assembly + Cholesky rounds per iteration that only the problems whose factorisation failed take part in) are in,
+// and so is the reference's own formulation: normal equations A Sigma^-1 A' of order m (opt.kkt_form = 1, LP only).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -41,12 +41,14 @@ enum { ST_ACTIVE = 0, ST_SOLVED = 1, ST_MAXITER = 6, ST_STEP_ERROR = -3, ST_INTE
 
 struct BQ {  // device view of the batch (by value in the kernel arguments); problem b at offset b * length
     int64_t B, nx, m, ns, n, nlb, nub, ntot, ldk, npad, kpad, nblk;
+    int64_t dim;     // order of the factorised matrix: nx (condensed) or m (normal equations)
+    int32_t normal;  // 1: the reference's NormalKKTSystem (src/KKT/normalkkt.jl), LP only
     const int64_t *ind_lb, *ind_ub, *ind_ineq, *slot;
     const double *H, *A, *q, *rhs, *c0;
     double *x, *xl, *xu, *zl, *zu, *y;
     double *f, *c, *jacl, *reg, *pr_diag, *du_diag, *d, *p, *w1, *w2;
     double *l_diag, *l_lower, *u_diag, *u_lower, *corr_lb, *corr_ub;
-    double *theta, *t, *u, *K, *S, *winv, *tmp;
+    double *theta, *t, *u, *K, *S, *winv, *tmp, *tn;
     double* scal;
     int32_t *status, *iters, *info, *retry_skip;
     madqp_mpc_options opt;
@@ -87,7 +89,7 @@ __device__ __forceinline__ madqp_state state_of(const BQ& q, int64_t b) {
 // per-problem pointers that are not part of madqp_state
 struct Prob {
     const double *H, *A, *qv, *rhs;
-    double *theta, *t, *u, *K, *S, *winv, *tmp, *w1, *scal;
+    double *theta, *t, *u, *K, *S, *winv, *tmp, *tn, *w1, *scal;
     double c0;
 };
 __device__ __forceinline__ Prob prob_of(const BQ& q, int64_t b) {
@@ -103,6 +105,7 @@ __device__ __forceinline__ Prob prob_of(const BQ& q, int64_t b) {
     p.S = q.S + b * q.kpad * q.npad;
     p.winv = q.winv + b * q.nblk * WBLK;
     p.tmp = q.tmp + b * q.npad;
+    p.tn = q.tn ? q.tn + b * q.n : nullptr;
     p.w1 = q.w1 + b * q.ntot;
     p.scal = q.scal + b * S_COUNT;
     p.c0 = q.c0[b];
@@ -169,9 +172,9 @@ int32_t dalloc(madqp_batch* b, T** p, int64_t count, bool zero = false) {
 int32_t factor_all(madqp_batch* b, const int32_t* skip) {
     madqp_ctx* ctx = b->ctx;
     const BQ& q = b->q;
-    if (q.nx == 0) return hipMemsetAsync(q.info, 0, q.B * sizeof(int32_t), ctx->stream) == hipSuccess
-                              ? MADQP_OK
-                              : MADQP_ERR_HIP;
+    if (q.dim == 0) return hipMemsetAsync(q.info, 0, q.B * sizeof(int32_t), ctx->stream) == hipSuccess
+                               ? MADQP_OK
+                               : MADQP_ERR_HIP;
     GemmArgs g{};
     g.X = q.S;
     g.ldx = q.npad;
@@ -181,23 +184,23 @@ int32_t factor_all(madqp_batch* b, const int32_t* skip) {
     g.Mread = g.Nread = q.npad;
     g.C = q.K;
     g.ldc = q.ldk;
-    g.Cin = q.H;
+    g.Cin = q.normal ? nullptr : q.H;
     g.ldcin = q.nx;
-    g.dvec = q.pr_diag;
+    g.dvec = q.normal ? q.theta : q.pr_diag;  // normal equations: Sigma_s^-1 on the inequality rows
     g.alpha = 1.0;
     g.beta = 1.0;
-    g.M = q.nx;
-    g.N = q.nx;
+    g.M = q.dim;
+    g.N = q.dim;
     g.lower_only = 1;
-    if (q.m == 0) {  // no constraints: K = H + Sigma through a K = 0 product is not worth a special case
+    if ((q.normal ? q.nx : q.m) == 0) {  // empty product: K = base + diagonal through a K = 0 product
         g.K = 0;
         g.X = g.Y = q.K;
         g.Mread = g.Nread = 0;
     }
-    GemmBatch bt{q.B, q.kpad * q.npad, q.kpad * q.npad, q.ldk * q.ldk, q.nx * q.nx, q.n, skip};
+    GemmBatch bt{q.B, q.kpad * q.npad, q.kpad * q.npad, q.ldk * q.ldk, q.nx * q.nx, q.normal ? q.m : q.n, skip};
     int32_t r = madqp_gemm_tn(ctx, g, MADQP_PROF_SYRK, nullptr, 0, &bt);
     if (r) return r;
-    return madqp_chol_factor_batched(ctx, q.K, q.ldk, q.nx, q.ldk * q.ldk, q.winv, q.nblk * WBLK, q.info, q.B, skip);
+    return madqp_chol_factor_batched(ctx, q.K, q.ldk, q.dim, q.ldk * q.ldk, q.winv, q.nblk * WBLK, q.info, q.B, skip);
 }
 }  // namespace
 
@@ -226,8 +229,11 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
                      (m == 0 || (data->A && data->rhs && data->y)) && data->c0);
     ARG_TRY(ctx, opt->step_rule >= 0 && opt->step_rule <= 2 && opt->max_ncorr >= 0 && opt->regularization >= 0 &&
                      opt->regularization <= 2);
+    const int32_t normal = opt->kkt_form;
+    ARG_TRY(ctx, normal == 0 || normal == 1);
+    ARG_TRY(ctx, !normal || !data->H);  // NormalKKTSystem supports only linear programs (src/KKT/normalkkt.jl:45-48)
     // the condensed form needs delta_d < 0 on equality rows (conventions)
-    ARG_TRY(ctx, ns == m || (opt->regularization != 0 && opt->delta_d < 0.0));
+    ARG_TRY(ctx, normal || ns == m || (opt->regularization != 0 && opt->delta_d < 0.0));
     *out = nullptr;
     madqp_batch* b = new (std::nothrow) madqp_batch();
     if (!b) return madqp_fail(ctx, MADQP_ERR_ALLOC, "host allocation failed");
@@ -245,9 +251,11 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
     q.nlb = nlb;
     q.nub = nub;
     q.ntot = q.n + m + nlb + nub;
-    q.npad = std::max<int64_t>(128, (nx + 127) / 128 * 128);
+    q.normal = normal;
+    q.dim = normal ? m : nx;
+    q.npad = std::max<int64_t>(128, (q.dim + 127) / 128 * 128);
     q.ldk = q.npad;
-    q.kpad = std::max<int64_t>(16, (m + 15) / 16 * 16);
+    q.kpad = std::max<int64_t>(16, ((normal ? nx : m) + 15) / 16 * 16);
     q.nblk = q.npad / 128;
     q.ind_lb = ind_lb;
     q.ind_ub = ind_ub;
@@ -301,6 +309,7 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
     BALLOC(q.S, B * q.kpad * q.npad);
     BALLOC(q.winv, B * q.nblk * WBLK, true);  // potf2_inv_kernel writes the lower parts only
     BALLOC(q.tmp, B * q.npad);
+    if (normal) BALLOC(q.tn, B * q.n);
     BALLOC(q.scal, B * S_COUNT, true);
     BALLOC(q.status, B, true);
     BALLOC(q.iters, B, true);

@@ -150,3 +150,32 @@ def test_batched_regularization_retry(hip):
         assert close(r["mu"], t["mu"], 1e-6) and close(r["del_w"], t["del_w"], 1e-12), i
         assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-6, i
     assert res[bad]["n_factorizations"] > res[0]["n_factorizations"]  # only the bad problem paid for retries
+
+
+def test_batched_normal_equations(hip):
+    """The reference's own NormalKKTSystem (src/KKT/normalkkt.jl: A Sigma^-1 A', LP only, equality rows without dual
+    regularization) inside the lock-step engine: problem by problem the oracle's normal-equations solve -- the case
+    of test/runtests.jl:165-180 (simple_lp-like: equality rows, default FixedRegularization(1e-8, 0))."""
+    qps = []
+    for i in range(6):
+        qp = Q.synthetic_qp(2100 + i, 40, 16, "lp")
+        qp.lcon[[1, 6]] = qp.ucon[[1, 6]] = 0.3  # equality rows
+        qps.append(qp)
+    reg, oreg = M.FixedRegularization(1e-8, 0.0), mpc.FixedRegularization(1e-8, 0.0)
+    s = M.BatchedMPCSolver([to_device(q, hip) for q in qps], hip, kkt_system="normal", regularization=reg)
+    res = s.solve()
+    s.close()
+    for i, (qp, r) in enumerate(zip(qps, res)):
+        ref = mpc.solve(qp, kkt_system="normal", regularization=oreg)
+        assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED, (i, r["status"], ref["status"])
+        assert r["iter"] == ref["iter"], (i, r["iter"], ref["iter"])
+        assert close(r["objective"], ref["objective"], 1e-9)
+        assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+        assert np.max(np.abs(r["multipliers"] - ref["multipliers"])) <= 1e-6
+    one = Q.simple_lp()  # test/runtests.jl:24-55, as a batch of one
+    s = M.BatchedMPCSolver([to_device(one, hip)], hip, kkt_system="normal", regularization=reg)
+    r = s.solve()[0]
+    s.close()
+    assert r["status"] == M.SOLVE_SUCCEEDED and abs(r["objective"] - 1.0) < 1e-8 and np.allclose(r["solution"], [0.5, 0.5], atol=1e-8)
+    with pytest.raises(ValueError):  # a QP: NormalKKTSystem supports only linear programs
+        M.BatchedMPCSolver([to_device(Q.synthetic_qp(1, 20, 8), hip)], hip, kkt_system="normal", regularization=reg)
