@@ -32,13 +32,11 @@ Rccl& rccl() {
     static bool tried = false;
     if (tried) return r;
     tried = true;
-    const char* names[] = {getenv("MADQP_RCCL_LIB"), "librccl.so", "librccl.so.1"};
-    for (const char* nm : names) {
-        if (!nm) continue;
-        r.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);  // the copy the process already uses (torch's)
-        if (!r.lib) r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (r.lib) break;
-    }
+    const char* names[] = {getenv("MADQP_RCCL_LIB"), "librccl.so.1", "librccl.so"};
+    for (const char* nm : names)  // first the copy the process already has (torch's): one RCCL per process
+        if (nm && !r.lib) r.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    for (const char* nm : names)
+        if (nm && !r.lib) r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     if (!r.lib) return r;
 #define RSYM(field, name) r.field = (decltype(r.field))dlsym(r.lib, name)
     RSYM(GetUniqueId, "ncclGetUniqueId");
