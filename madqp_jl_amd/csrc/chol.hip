@@ -365,6 +365,30 @@ __device__ __forceinline__ void sweep_poll_block(const double* __restrict__ x, i
     dst[2 * lane + 1] = (i0 + 1 < n) ? __longlong_as_double(u1) : 0.0;
 }
 
+// A long block row is streamed by several workgroups (madqp_chol_create builds the job list): job (r, c) takes the
+// tiles c*chunk .. min(r, (c+1)*chunk) - 1 of block r (counted from the far end of the dependency chain); the job
+// holding the tile next to the diagonal owns the block, the others publish their 128 partial sums to
+// part[(r*maxc + c)*128 ..] the way solution blocks are published.  jobs == nullptr: one job per block.
+struct SweepPlan {
+    const int32_t* jobs;  // ticket -> r | c << 20, ordered by (r, c): a job waits only for earlier tickets
+    double* part;
+    int32_t chunk, maxc;
+};
+
+// one published value (sentinel until its producer has stored it)
+__device__ __forceinline__ double sweep_poll_one(const double* p, double* __restrict__ err) {
+    unsigned long long u = ld_sc1_u64(p);
+    int spins = 0;
+    while (u == SWEEP_SENTINEL) {
+        if (++spins > SWEEP_SPIN_LIMIT) {
+            *err = 1.0;
+            return __longlong_as_double(0x7FF8000000000000ull);
+        }
+        u = ld_sc1_u64(p);
+    }
+    return __longlong_as_double(u);
+}
+
 // half a 128 x 128 column-major tile: rows 2*lane, 2*lane+1 and the 4 columns of this wave
 __device__ __forceinline__ void sweep_load_half(const double* __restrict__ base, int64_t ld, bool ok0,
                                                 bool ok1, bool vec, double2_t (&dst)[4]) {
@@ -415,7 +439,7 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
                                                               const double* __restrict__ b,
                                                               double* __restrict__ y, int64_t n,
                                                               int32_t* __restrict__ ctl, double* __restrict__ fault,
-                                                              int vec) {
+                                                              int vec, SweepPlan plan) {
     __shared__ double xs[2][NB];
     __shared__ double red[16][NB];
     __shared__ double vs[NB];
@@ -423,13 +447,21 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_r = atomicAdd(&ctl[1], 1);
     __syncthreads();
-    const int r = s_r;
+    int r = s_r, c = 0, j0 = 0, j1 = r;
+    if (plan.jobs) {
+        const int32_t job = plan.jobs[r];
+        r = job & 0xFFFFF;
+        c = job >> 20;
+        j0 = c * plan.chunk;
+        j1 = (j0 + plan.chunk < r) ? j0 + plan.chunk : r;
+    }
+    const bool owner = (j1 == r);
     const int64_t row0 = (int64_t)r * NB;
     const int w = (int)((n - row0 < NB) ? (n - row0) : NB);
     const bool ok0 = row0 + 2 * lane < n, ok1 = row0 + 2 * lane + 1 < n;
     // inverse diagonal block (column-major image, zero padded, 16-byte aligned): registers
     double2_t W0[4], W1[4];
-    {
+    if (owner) {
         const double* Wcm = winv + (int64_t)r * WBLK + 2 * lane;
         sweep_load_half(Wcm + (int64_t)(wave * 4) * NB, NB, true, true, true, W0);
         sweep_load_half(Wcm + (int64_t)(64 + wave * 4) * NB, NB, true, true, true, W1);
@@ -437,8 +469,8 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     double a0 = 0.0, a1 = 0.0;
     const double* Lr = L + row0 + 2 * lane + (int64_t)(wave * 4) * lda;  // this thread's corner of tile (r, 0)
     double2_t A[4], B[4];
-    if (r > 0) sweep_load_half(Lr, lda, ok0, ok1, vec, A);
-    for (int j = 0; j < r; ++j) {
+    if (j1 > j0) sweep_load_half(Lr + (int64_t)j0 * NB * lda, lda, ok0, ok1, vec, A);
+    for (int j = j0; j < j1; ++j) {
         const double* Tj = Lr + (int64_t)j * NB * lda;
         sweep_load_half(Tj + 64 * lda, lda, ok0, ok1, vec, B);
         if (wave == 0) sweep_poll_block(y, j, n, xs[j & 1], fault, lane);
@@ -450,7 +482,7 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
             a0 = __builtin_fma(A[q].x, xv, a0);
             a1 = __builtin_fma(A[q].y, xv, a1);
         }
-        if (j + 1 < r) sweep_load_half(Tj + (int64_t)NB * lda, lda, ok0, ok1, vec, A);
+        if (j + 1 < j1) sweep_load_half(Tj + (int64_t)NB * lda, lda, ok0, ok1, vec, A);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double xv = xj[64 + wave * 4 + q];
@@ -462,15 +494,19 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     red[wave][2 * lane + 1] = a1;
     __syncthreads();
     if (tid < NB) {
-        double v = 0.0;
-        if (tid < w) {
-            double sum = red[0][tid];
+        double sum = red[0][tid];
 #pragma unroll
-            for (int q = 1; q < 16; ++q) sum += red[q][tid];
-            v = b[row0 + tid] - sum;
+        for (int q = 1; q < 16; ++q) sum += red[q][tid];
+        if (!owner) {
+            st_sc1_f64(plan.part + ((int64_t)r * plan.maxc + c) * NB + tid, sum);
+        } else {
+            double far = 0.0;  // the partial sums of this block's other jobs, in column order
+            for (int cc = 0; cc < c; ++cc)
+                far += sweep_poll_one(plan.part + ((int64_t)r * plan.maxc + cc) * NB + tid, fault);
+            vs[tid] = (tid < w) ? (b[row0 + tid] - (far + sum)) : 0.0;
         }
-        vs[tid] = v;
     }
+    if (!owner) return;
     __syncthreads();
     sweep_diag_publish(W0, W1, vs, red, y, row0, w, tid, lane, wave);
 }
@@ -480,7 +516,7 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
                                                               const double* __restrict__ y,
                                                               double* __restrict__ x, int64_t n,
                                                               int32_t* __restrict__ ctl, double* __restrict__ fault,
-                                                              int vec) {
+                                                              int vec, SweepPlan plan) {
     __shared__ double xs[2][NB];
     __shared__ double red[16][NB];
     __shared__ double vs[NB];
@@ -488,14 +524,24 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
     __shared__ int s_r;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = (int)((n + NB - 1) / NB);
-    if (tid == 0) s_r = nblk - 1 - atomicAdd(&ctl[2], 1);
+    if (tid == 0) s_r = atomicAdd(&ctl[2], 1);
     __syncthreads();
-    const int r = s_r;
+    // block nblk-1-rr has rr tiles below its diagonal block; the job takes tiles k0 .. k1-1 counted from the last row
+    int rr = s_r, c = 0, k0 = 0, k1 = rr;
+    if (plan.jobs) {
+        const int32_t job = plan.jobs[rr];
+        rr = job & 0xFFFFF;
+        c = job >> 20;
+        k0 = c * plan.chunk;
+        k1 = (k0 + plan.chunk < rr) ? k0 + plan.chunk : rr;
+    }
+    const bool owner = (k1 == rr);
+    const int r = nblk - 1 - rr;
     const int64_t col0 = (int64_t)r * NB;
     const int w = (int)((n - col0 < NB) ? (n - col0) : NB);
     // W' v through the row-major image: Wrm[c + r*NB] = W(r, c) -> output index c is the fast one
     double2_t W0[4], W1[4];
-    {
+    if (owner) {
         const double* Wrm = winv + (int64_t)r * WBLK + NB * NB + 2 * lane;
         sweep_load_half(Wrm + (int64_t)(wave * 4) * NB, NB, true, true, true, W0);
         sweep_load_half(Wrm + (int64_t)(64 + wave * 4) * NB, NB, true, true, true, W1);
@@ -506,23 +552,21 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[h][q] = 0.0;
-    const bool colok = true;  // blocks left of the last one are whole; block r's own columns < n hold below
-    (void)colok;
     const double* Lc = L + 2 * lane + (col0 + wave * 4) * lda;  // + row block offset
     double2_t A[4], B[4];
-    const int jlast = nblk - 1;
+    const int jhi = nblk - 1 - k0, jlo = nblk - 1 - k1;  // row blocks jhi, jhi-1, .., jlo+1
     auto rows_ok = [&](int j, bool& o0, bool& o1) {
         const int64_t i0 = (int64_t)j * NB + 2 * lane;
         o0 = i0 < n;
         o1 = i0 + 1 < n;
     };
-    // columns of block r beyond n do not exist only when r is the last block: then there are no tiles
-    if (r < jlast) {
+    // (the columns of block r all exist whenever it has tiles: only the last block can be short)
+    if (jhi > jlo) {
         bool o0, o1;
-        rows_ok(jlast, o0, o1);
-        sweep_load_half(Lc + (int64_t)jlast * NB, lda, o0, o1, vec, A);
+        rows_ok(jhi, o0, o1);
+        sweep_load_half(Lc + (int64_t)jhi * NB, lda, o0, o1, vec, A);
     }
-    for (int j = jlast; j > r; --j) {
+    for (int j = jhi; j > jlo; --j) {
         bool o0, o1;
         rows_ok(j, o0, o1);
         const double* Tj = Lc + (int64_t)j * NB;
@@ -532,7 +576,7 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
         const double x0 = xs[j & 1][2 * lane], x1 = xs[j & 1][2 * lane + 1];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[0][q] = __builtin_fma(A[q].y, x1, __builtin_fma(A[q].x, x0, acc[0][q]));
-        if (j - 1 > r) {
+        if (j - 1 > jlo) {
             bool p0, p1;
             rows_ok(j - 1, p0, p1);
             sweep_load_half(Tj - NB, lda, p0, p1, vec, A);
@@ -550,17 +594,26 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
         for (int q = 0; q < 4; ++q) colred[h * 64 + wave * 4 + q][lane] = acc[h][q];
     __syncthreads();
     {
-        const int c = tid >> 3, part = tid & 7;
+        const int cl = tid >> 3, part = tid & 7;
         double t = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t += colred[c][part * 8 + u];
+        for (int u = 0; u < 8; ++u) t += colred[cl][part * 8 + u];
         t += __shfl_down(t, 4, 8);
         t += __shfl_down(t, 2, 8);
         t += __shfl_down(t, 1, 8);
-        if (part == 0) vs[c] = t;
+        if (part == 0) vs[cl] = t;
     }
     __syncthreads();
-    if (tid < NB) vs[tid] = (tid < w) ? (y[col0 + tid] - vs[tid]) : 0.0;
+    if (!owner) {
+        if (tid < NB) st_sc1_f64(plan.part + ((int64_t)rr * plan.maxc + c) * NB + tid, vs[tid]);
+        return;
+    }
+    if (tid < NB) {
+        double far = 0.0;
+        for (int cc = 0; cc < c; ++cc)
+            far += sweep_poll_one(plan.part + ((int64_t)rr * plan.maxc + cc) * NB + tid, fault);
+        vs[tid] = (tid < w) ? (y[col0 + tid] - (far + vs[tid])) : 0.0;
+    }
     __syncthreads();
     sweep_diag_publish(W0, W1, vs, red, x, col0, w, tid, lane, wave);
 }
@@ -579,11 +632,34 @@ extern "C" int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out
     s->lda = 0;
     s->winv = nullptr;
     s->tmp = nullptr;
+    s->d_jobs = nullptr;
     s->d_info = nullptr;
     const int64_t nblk = std::max<int64_t>(1, (n + NB - 1) / NB);
     hipError_t e = hipMalloc(&s->winv, nblk * WBLK * sizeof(double));
     if (e == hipSuccess) e = hipMemset(s->winv, 0, nblk * WBLK * sizeof(double));  // the kernel writes lower parts only
-    if (e == hipSuccess) e = hipMalloc(&s->tmp, std::max<int64_t>(NB, n) * sizeof(double));
+    // sweeps: block rows longer than `chunk` tiles are streamed by several workgroups (SweepPlan).  tmp holds the
+    // intermediate vector (padded to whole blocks) followed by the partial-sum slots of both sweeps, so that one fill
+    // per solve resets all of them.
+    s->sweep_chunk = 64;
+    if (const char* e_chunk = getenv("MADQP_SWEEP_CHUNK")) s->sweep_chunk = std::max(1, atoi(e_chunk));
+    s->sweep_maxc = 0;
+    s->sweep_njobs = 0;
+    s->d_jobs = nullptr;
+    std::vector<int32_t> jobs;
+    if (nblk - 1 > s->sweep_chunk && nblk < (1 << 20)) {
+        s->sweep_maxc = (int32_t)((nblk - 1 + s->sweep_chunk - 1) / s->sweep_chunk);
+        for (int64_t r = 0; r < nblk; ++r) {
+            const int64_t nc = std::max<int64_t>(1, (r + s->sweep_chunk - 1) / s->sweep_chunk);
+            for (int64_t c = 0; c < nc; ++c) jobs.push_back((int32_t)(r | (c << 20)));
+        }
+        s->sweep_njobs = (int32_t)jobs.size();
+    }
+    s->tmp_len = nblk * NB + 2 * nblk * (int64_t)s->sweep_maxc * NB;
+    if (e == hipSuccess) e = hipMalloc(&s->tmp, s->tmp_len * sizeof(double));
+    if (e == hipSuccess && !jobs.empty()) {
+        e = hipMalloc(&s->d_jobs, jobs.size() * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemcpy(s->d_jobs, jobs.data(), jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc(&s->d_info, 8 * sizeof(int32_t));  // [0] info, [1..2] sweep tickets
     if (e != hipSuccess) {
         madqp_chol_destroy(s);
@@ -610,6 +686,7 @@ extern "C" int32_t madqp_chol_destroy(madqp_chol* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->winv) (void)hipFree(s->winv);
     if (s->tmp) (void)hipFree(s->tmp);
+    if (s->d_jobs) (void)hipFree(s->d_jobs);
     if (s->d_info) (void)hipFree(s->d_info);
     delete s;
     return MADQP_OK;
@@ -998,10 +1075,10 @@ int32_t madqp_trsv_tile(madqp_ctx* ctx, int32_t trans, const double* L, int64_t 
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)tmp, 0x7FF8A5A5, 2 * (size_t)w, ctx->stream));
     if (!trans)
         hipLaunchKernelGGL(trsv_fwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, L, ld, winv, v, tmp, w, ctl,
-                           ctx->d_res + MADQP_FAULT_SLOT, vec);
+                           ctx->d_res + MADQP_FAULT_SLOT, vec, SweepPlan{nullptr, nullptr, 0, 0});
     else
         hipLaunchKernelGGL(trsv_bwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, L, ld, winv, v, tmp, w, ctl,
-                           ctx->d_res + MADQP_FAULT_SLOT, vec);
+                           ctx->d_res + MADQP_FAULT_SLOT, vec, SweepPlan{nullptr, nullptr, 0, 0});
     LAUNCH_CHECK(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(v, tmp, (size_t)w * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return MADQP_OK;
@@ -1020,10 +1097,16 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
         // one launch per sweep (see trsv_*_sweep_kernel): y = L^-1 b into s->tmp, x = L^-T y into rhs
         const unsigned nblk = (unsigned)((n + NB - 1) / NB);
         const int vec = ((((uintptr_t)A) & 15) == 0) && (lda % 2 == 0);
+        const int64_t nb64 = nblk;
+        const unsigned grid = s->d_jobs ? (unsigned)s->sweep_njobs : nblk;
+        double* part_f = s->tmp + nb64 * NB;
+        double* part_b = part_f + nb64 * s->sweep_maxc * NB;
+        const SweepPlan pf{s->d_jobs, part_f, s->sweep_chunk, s->sweep_maxc};
+        const SweepPlan pb{s->d_jobs, part_b, s->sweep_chunk, s->sweep_maxc};
         HIP_TRY(ctx, hipMemsetAsync(s->d_info + 1, 0, 3 * sizeof(int32_t), ctx->stream));
-        HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)s->tmp, 0x7FF8A5A5, 2 * (size_t)n, ctx->stream));
-        hipLaunchKernelGGL(trsv_fwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, A, lda, s->winv, rhs,
-                           s->tmp, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec);
+        HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)s->tmp, 0x7FF8A5A5, 2 * (size_t)s->tmp_len, ctx->stream));
+        hipLaunchKernelGGL(trsv_fwd_sweep_kernel, dim3(grid), dim3(1024), 0, ctx->stream, A, lda, s->winv, rhs,
+                           s->tmp, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec, pf);
         LAUNCH_CHECK(ctx);
         if (s->npos < n) {  // y <- diag(I, -I) y
             const int64_t len = n - s->npos;
@@ -1032,8 +1115,8 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
             LAUNCH_CHECK(ctx);
         }
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)rhs, 0x7FF8A5A5, 2 * (size_t)n, ctx->stream));
-        hipLaunchKernelGGL(trsv_bwd_sweep_kernel, dim3(nblk), dim3(1024), 0, ctx->stream, A, lda, s->winv,
-                           s->tmp, rhs, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec);
+        hipLaunchKernelGGL(trsv_bwd_sweep_kernel, dim3(grid), dim3(1024), 0, ctx->stream, A, lda, s->winv, s->tmp, rhs,
+                           n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec, pb);
         LAUNCH_CHECK(ctx);
     }
     return MADQP_OK;

@@ -150,7 +150,10 @@ struct madqp_chol {
     madqp_ctx* ctx;
     int64_t n;
     double* winv;  // ceil(n/128) blocks of 128x128 (col-major, ld 128): inverse diagonal blocks
-    double* tmp;   // n doubles
+    double* tmp;   // tmp_len doubles: the intermediate vector of a solve, then the sweeps' partial-sum slots
+    int64_t tmp_len;
+    int32_t* d_jobs;  // sweep job list (chol.hip SweepPlan), nullptr when every block row is one job
+    int32_t sweep_chunk, sweep_maxc, sweep_njobs;
     int32_t* d_info;
     double* A;  // last factored matrix (borrowed)
     int64_t lda;
