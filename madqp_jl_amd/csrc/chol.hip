@@ -35,6 +35,7 @@ constexpr int LDS_LD = P2_LDS_LD;
 constexpr int64_t WBLK = 2 * NB * NB;  // doubles per block in chol->winv: [Wcm | Wrm]
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+#include "gemm_core.inc"
 constexpr int SB = 16;             // sub-block of the diagonal kernel (one MFMA tile)
 constexpr int NSB = NB / SB;       // 8 sub-block columns
 constexpr int WD_LD = SB + 1;      // row stride of the inverse diagonal sub-blocks
@@ -140,25 +141,18 @@ struct Potf2Batch {  // problem blockIdx.x: pointer strides (doubles / ints); sk
 };
 constexpr int P2_THREADS = 512;  // wave 0: the chain of 16 x 16 diagonal factorisations; waves 1..7: everything else
 // (1024 threads: loads and stores faster, the steps slower -- 45.2 vs 44.4 us)
-__global__ __launch_bounds__(P2_THREADS) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int nb,
-                                                        double* __restrict__ Wcm,
-                                                        double* __restrict__ Wrm,
-                                                        int32_t* __restrict__ info, int32_t col0,
-                                                        Potf2Batch bt) {
-    if (gridDim.x > 1 || bt.skip) {
-        const int64_t b = blockIdx.x;
-        if (bt.skip && bt.skip[b] != 0) return;
-        A += b * bt.sA;
-        Wcm += b * bt.sW;
-        Wrm += b * bt.sW;
-        info += b * bt.sInfo;
-    }
-    __shared__ double S[NB * LDS_LD];           // S[c*LDS_LD + r] = element (r, c)
-    __shared__ double Wd[NSB * SB * WD_LD];     // inverse diagonal sub-blocks
+constexpr int P2_S_DOUBLES = NB * LDS_LD;         // S[c*LDS_LD + r] = element (r, c)
+constexpr int P2_WD_DOUBLES = NSB * SB * WD_LD;   // inverse diagonal sub-blocks
+// the whole workgroup (P2_THREADS threads) calls this; S and Wd are its LDS work areas
+__device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t lda, int nb,
+                                               double* __restrict__ Wcm, double* __restrict__ Wrm,
+                                               int32_t* __restrict__ info, int32_t col0,
+                                               double* __restrict__ S, double* __restrict__ Wd,
+                                               bool tile_in_lds = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     P2_STAMP(0);
-    {  // lower triangle -> LDS: row r = tid & 127, columns (tid >> 7) + CG*i; all loads of a thread in flight at
+    if (!tile_in_lds) {  // lower triangle -> LDS: row r = tid & 127, columns (tid >> 7) + CG*i; all loads of a thread in flight at
         // once (one HBM / L2 latency; the kernel runs alone on its CU, registers are free)
         constexpr int CG = P2_THREADS / NB;
         const int r = tid & (NB - 1), c0 = tid >> 7;
@@ -306,6 +300,24 @@ __global__ __launch_bounds__(P2_THREADS) void potf2_inv_kernel(double* __restric
         }
     }
     P2_STAMP(28);
+}
+
+__global__ __launch_bounds__(P2_THREADS) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int nb,
+                                                        double* __restrict__ Wcm,
+                                                        double* __restrict__ Wrm,
+                                                        int32_t* __restrict__ info, int32_t col0,
+                                                        Potf2Batch bt) {
+    if (gridDim.x > 1 || bt.skip) {
+        const int64_t b = blockIdx.x;
+        if (bt.skip && bt.skip[b] != 0) return;
+        A += b * bt.sA;
+        Wcm += b * bt.sW;
+        Wrm += b * bt.sW;
+        info += b * bt.sInfo;
+    }
+    __shared__ double S[P2_S_DOUBLES];
+    __shared__ double Wd[P2_WD_DOUBLES];
+    potf2_inv_body(A, lda, nb, Wcm, Wrm, info, col0, S, Wd);
 }
 
 // ---- triangular sweeps, one launch each ---------------------------------------------------------
@@ -617,6 +629,142 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
     __syncthreads();
     sweep_diag_publish(W0, W1, vs, red, x, col0, w, tid, lane, wave);
 }
+
+// ---- mid-size factorisation: right-looking, two launches per 128-column block ---------------------------------
+// Below n ~ 10 000 the left-looking schedule above is a chain of short dependent launches (per block: update with
+// split-K, its reduction, the diagonal kernel, panel times inverse -- 120 us, of which the matrix pipes are busy a
+// fraction).  Here step k is
+//   chol_mid_step_kernel  every tile (i, j), k <= j <= i, receives the update of panel k-1: C_ij -= L_i,k-1 L_j,k-1'
+//                         (K = 128 always, no split-K; a tile accumulates its updates in the order k = 0, 1, ..), and
+//                         the workgroup holding tile (k, k) goes on to factor and invert it without leaving the CU:
+//                         the updated tile passes from the accumulators to the LDS image of potf2_inv_body;
+//   panel times inverse   L_ik = C_ik W_k' (the GEMM kernel, as in factor_block).
+// Workgroups have 512 threads and the diagonal kernel's LDS (one per CU).  With more tiles than CUs a workgroup
+// runs two tiles at once: waves 0-3 and waves 4-7 each work like one workgroup of gemm_tn_f64_kernel on their own
+// half of the LDS, in lockstep (both products have K = 128: both halves execute the same barriers).
+struct MidArgs {
+    double* A;
+    int64_t lda, n;
+    int32_t nblk, k;
+    int32_t pack;  // tiles per workgroup (1 or 2); the diagonal tile always has its workgroup to itself
+    double* winv;
+    int32_t* info;
+};
+#ifdef MADQP_MID_STAMPS
+__device__ unsigned long long madqp_mid_stamps[64][16];  // diagnostic build only (tools/mid_probe.cpp)
+#define MID_STAMP(slot)                                                                                              \
+    do {                                                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x <= 1)                                                                     \
+            madqp_mid_stamps[a.k & 63][8 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime();                  \
+    } while (0)
+#else
+#define MID_STAMP(slot)
+#endif
+constexpr int MID_THREADS = 512;
+constexpr int MID_BARRIERS = NB / BK + 1;  // barriers of one K = 128 main loop (both flavours)
+
+__global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
+    __shared__ __attribute__((aligned(16))) double smem[P2_S_DOUBLES + P2_WD_DOUBLES];
+    static_assert(P2_S_DOUBLES + P2_WD_DOUBLES >= 8 * TILE_DOUBLES, "two GEMM halves fit the diagonal kernel's LDS");
+    static_assert(MID_THREADS == P2_THREADS, "potf2_inv_body is written for P2_THREADS threads");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, w4 = wave & 3;
+    const int wi = w4 & 1, wj = w4 >> 1;
+    const int lo = lane & 15, hi = lane >> 4;
+    const int k = a.k, rem = a.nblk - k;
+    const bool diag = (blockIdx.x == 0);
+    MID_STAMP(0);
+    // tile t = i'(i'+1)/2 + j' (0 <= j' <= i' < rem) is (k + i', k + j'); t = 0, the diagonal tile, is workgroup 0
+    const int ntiles = rem * (rem + 1) / 2;
+    const int t = diag ? 0 : 1 + a.pack * ((int)blockIdx.x - 1) + half;
+    const bool active = diag ? (half == 0) : (t < ntiles && half < a.pack);
+    int ip = 0, jp = 0;
+    if (active && !diag) {
+        ip = (int)((sqrtf(1.0f + 8.0f * (float)t) - 1.0f) * 0.5f);
+        while (ip * (ip + 1) / 2 > t) --ip;
+        while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
+        jp = t - ip * (ip + 1) / 2;
+    }
+    ip = __builtin_amdgcn_readfirstlane(ip);  // wave-uniform: the LDS-DMA rows are addressed from scalar registers
+    jp = __builtin_amdgcn_readfirstlane(jp);
+    const int64_t i0 = (int64_t)(k + ip) * NB, j0 = (int64_t)(k + jp) * NB;
+    const int64_t npad = (int64_t)a.nblk * NB;
+    double* lds = smem + half * (4 * TILE_DOUBLES);
+    double4_t acc[4][4];
+
+    if (k > 0) {
+        GemmArgs g{};
+        g.X = a.A + (int64_t)(k - 1) * NB * a.lda;
+        g.Y = g.X;
+        g.ldx = g.ldy = a.lda;
+        g.M = g.N = a.n;
+        g.Mread = g.Nread = npad;
+        g.K = NB;
+        if (!active) {  // the other half of the workgroup has a tile: keep its barriers company
+            for (int b = 0; b < MID_BARRIERS; ++b) __builtin_amdgcn_s_barrier();
+        } else {
+            // the accumulators start at -C_ij (loads in flight while the first stage is staged; rows up to the padded
+            // order exist, what lies beyond n or above the diagonal is never stored) and come back negated
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        int64_t gj = j0 + wj * 64 + tj * 16 + hi + 4 * v;
+                        gj = (gj < a.n) ? gj : a.n - 1;  // columns beyond n: any value will do, no branch
+                        acc[ti][tj][v] = -a.A[i0 + wi * 64 + ti * 16 + lo + gj * a.lda];
+                    }
+            mainloop_dma(g, i0, j0, lds, wi, wj, lane, w4, acc);
+        }
+        MID_STAMP(1);
+        if (active && !diag) {
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+                const int64_t gi = i0 + wi * 64 + ti * 16 + lo;
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int64_t gj = j0 + wj * 64 + tj * 16 + hi + 4 * v;
+                        if (gi < a.n && gj < a.n && gi >= gj) a.A[gi + gj * a.lda] = -acc[ti][tj][v];
+                    }
+                }
+            }
+        }
+    }
+    if (!diag) return;
+
+    // the diagonal tile: accumulators -> LDS image S[c*LDS_LD + r] (lower triangle, identity padding), factor, invert
+    double* S = smem;
+    const int nb = (int)((a.n - i0 < NB) ? (a.n - i0) : NB);
+    if (k > 0) {
+        // (the main loop ends with a barrier after its last LDS read: the staging buffers are free)
+        if (half == 0) {
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+                const int r = wi * 64 + ti * 16 + lo;
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int c = wj * 64 + tj * 16 + hi + 4 * v;
+                        double x = -acc[ti][tj][v];
+                        if (r >= nb || c >= nb) x = (r == c) ? 1.0 : 0.0;
+                        S[c * LDS_LD + r] = (r >= c) ? x : 0.0;  // the upper triangle is the inverse's work area
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    MID_STAMP(2);
+    double* Wcm = a.winv + (int64_t)k * WBLK;
+    potf2_inv_body(a.A + i0 + i0 * a.lda, a.lda, nb, Wcm, Wcm + NB * NB, a.info, (int32_t)i0, S, smem + P2_S_DOUBLES,
+                   /*tile_in_lds=*/k > 0);
+    MID_STAMP(3);
+}
 }  // namespace
 
 extern "C" int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out) {
@@ -810,6 +958,48 @@ extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int3
         return MADQP_OK;
     }
     HIP_TRY(ctx, hipMemsetAsync(s->d_info, 0, sizeof(int32_t), ctx->stream));
+    // mid-size matrices: right-looking, two launches per 128-column block (chol_mid_step_kernel)
+    static const int64_t mid_max = getenv("MADQP_CHOL_MID_MAX") ? atoll(getenv("MADQP_CHOL_MID_MAX")) : 0;
+    const int64_t npad_m = (n + NB - 1) / NB * NB;
+    if (n <= mid_max && n > NB && s->npos == n && lda >= npad_m && lda % 2 == 0 && (((uintptr_t)A) & 15) == 0) {
+        const int32_t nblk = (int32_t)(npad_m / NB);
+        for (int32_t k = 0; k < nblk; ++k) {
+            {
+                ProfScope ps(ctx, MADQP_PROF_POTRF_GEMM);
+                const int64_t rem = nblk - k, ntiles = (k > 0) ? rem * (rem + 1) / 2 : 1;
+                const int32_t pack = (ntiles > ctx->gemm_slots / 2) ? 2 : 1;
+                const unsigned grid = (unsigned)(1 + (ntiles - 1 + pack - 1) / pack);
+                hipLaunchKernelGGL(chol_mid_step_kernel, dim3(grid), dim3(MID_THREADS), 0, ctx->stream,
+                                   MidArgs{A, lda, n, nblk, k, pack, s->winv, s->d_info});
+                LAUNCH_CHECK(ctx);
+            }
+            const int64_t jb = (int64_t)k * NB;
+            if (jb + NB < n) {  // L[below, jb] = C[below, jb] W_k'  (see factor_block)
+                GemmArgs g{};
+                g.X = A + (jb + NB) + jb * lda;
+                g.ldx = lda;
+                g.Y = s->winv + (int64_t)k * WBLK;
+                g.ldy = NB;
+                g.C = A + (jb + NB) + jb * lda;
+                g.ldc = lda;
+                g.alpha = 1.0;
+                g.beta = 0.0;
+                g.M = n - jb - NB;
+                g.N = NB;
+                g.K = NB;
+                g.Mread = npad_m - jb - NB;
+                g.Nread = NB;
+                const int32_t r = madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_TRSM);
+                if (r) return r;
+            }
+        }
+        int32_t info_m = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&info_m, s->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        *info_host = info_m;
+        s->factored = (info_m == 0);
+        return MADQP_OK;
+    }
     // Quasi-definite mode (npos < n): A = [P, .; B, -Q] with P, Q positive definite and Q's block STORED AS +Q.
     // A = L diag(I, -I) L' with L = [L11, 0; W, L22], W = B L11^-T, L22 L22' = Q + W W': the same left-looking
     // sweep, except that an outer panel of the second block receives the columns of the first with a plus sign

@@ -42,8 +42,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 144, NTHREADS = 256;
-constexpr int TILE_DOUBLES = BK * LDT;
+#include "gemm_core.inc"
 
 struct KArgs {
     GemmArgs g;
@@ -61,223 +60,6 @@ struct KArgs {
     unsigned long long* stamps;  // diagnostic build only (tools/gemm_probe): per-workgroup clocks
 #endif
 };
-
-// register-staged loader (edge tiles, unaligned operands): bounds checks and zero fill
-template <bool GUARD>
-__device__ __forceinline__ void load_stage(const double* __restrict__ P, int64_t ld, int64_t r0,
-                                           int64_t R, int64_t k0, int64_t K, double2_t (&regs)[4],
-                                           int tid) {
-    const int col = (tid & 63) * 2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t k = k0 + r * 4 + (tid >> 6);
-        double2_t v;
-        if (GUARD) {
-            v.x = 0.0;
-            v.y = 0.0;
-            if (k < K) {
-                const double* p = P + k * ld + r0 + col;
-                if (r0 + col < R) v.x = p[0];
-                if (r0 + col + 1 < R) v.y = p[1];
-            }
-        } else {
-            v = *reinterpret_cast<const double2_t*>(P + k * ld + r0 + col);
-        }
-        regs[r] = v;
-    }
-}
-
-__device__ __forceinline__ void store_stage(double* __restrict__ T, const double2_t (&regs)[4],
-                                            int tid) {
-    const int col = (tid & 63) * 2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int kr = r * 4 + (tid >> 6);
-        *reinterpret_cast<double2_t*>(T + kr * LDT + col) = regs[r];
-    }
-}
-
-__device__ __forceinline__ void compute_stage(const double* __restrict__ Xs,
-                                              const double* __restrict__ Ys, int wi, int wj,
-                                              int lane, double4_t (&acc)[4][4]) {
-    const int lo = lane & 15, hi = lane >> 4;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const int kr = kk * 4 + hi;
-        double a[4], b[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = Ys[kr * LDT + wj * 64 + t * 16 + lo];
-            b[t] = Xs[kr * LDT + wi * 64 + t * 16 + lo];
-        }
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tj], b[ti], acc[ti][tj], 0, 0, 0);
-    }
-}
-
-// edge tiles: global -> registers -> LDS
-__device__ __forceinline__ void mainloop_staged(const GemmArgs& g, int64_t i0, int64_t j0, double* lds,
-                                                int tid, int wi, int wj, int lane,
-                                                double4_t (&acc)[4][4]) {
-    double* Xs = lds;                     // [2][BK][LDT]
-    double* Ys = lds + 2 * TILE_DOUBLES;  // [2][BK][LDT]
-    const int64_t nstage = (g.K + BK - 1) / BK;
-    double2_t xr[4], yr[4];
-    if (nstage > 0) {
-        load_stage<true>(g.X, g.ldx, i0, g.M, 0, g.K, xr, tid);
-        load_stage<true>(g.Y, g.ldy, j0, g.N, 0, g.K, yr, tid);
-        store_stage(Xs, xr, tid);
-        store_stage(Ys, yr, tid);
-    }
-    __syncthreads();
-    for (int64_t st = 0; st < nstage; ++st) {
-        const int buf = (int)(st & 1);
-        const bool more = st + 1 < nstage;
-        if (more) {
-            load_stage<true>(g.X, g.ldx, i0, g.M, (st + 1) * BK, g.K, xr, tid);
-            load_stage<true>(g.Y, g.ldy, j0, g.N, (st + 1) * BK, g.K, yr, tid);
-        }
-        compute_stage(Xs + buf * TILE_DOUBLES, Ys + buf * TILE_DOUBLES, wi, wj, lane, acc);
-        if (more) {
-            store_stage(Xs + (buf ^ 1) * TILE_DOUBLES, xr, tid);
-            store_stage(Ys + (buf ^ 1) * TILE_DOUBLES, yr, tid);
-        }
-        __syncthreads();
-    }
-}
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// ---- interior-tile main loop: no vector-ALU instruction between the MFMAs -----------------
-// Measured on gfx950 (tools/mfma_probe.hip): one VALU instruction per fp64 MFMA costs ~13 cycles
-// of matrix pipe, LDS reads cost none.  So the steady-state loop uses
-//   * ds_read_b64 with 16-bit immediate offsets from two per-lane base registers (no address adds),
-//   * global_load_lds_dwordx4 in the saddr form: scalar row pointer + constant per-lane offset,
-//     LDS destination through M0 -- all address arithmetic is on the scalar unit,
-//   * counted s_waitcnt written by hand (the compiler does not see inline-asm memory operations).
-constexpr int ROW_BYTES = LDT * 8;          // 1152
-constexpr int TILE_BYTES = BK * ROW_BYTES;  // 18432
-constexpr int Y_BYTES = 2 * TILE_BYTES;     // Y tiles start after the two X buffers
-
-template <int OFF>
-__device__ __forceinline__ double lds_read(unsigned base) {
-    double d;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(base), "n"(OFF));
-    return d;
-}
-
-// fragments of k-step KK (4 k's) of the buffer the bases point into: a <- Y tile, b <- X tile
-template <int KK>
-__device__ __forceinline__ void read_frags(unsigned vx, unsigned vy, double (&a)[4], double (&b)[4]) {
-    constexpr int o = KK * 4 * ROW_BYTES;
-    a[0] = lds_read<o + 0 * 128>(vy);
-    a[1] = lds_read<o + 1 * 128>(vy);
-    a[2] = lds_read<o + 2 * 128>(vy);
-    a[3] = lds_read<o + 3 * 128>(vy);
-    b[0] = lds_read<o + 0 * 128>(vx);
-    b[1] = lds_read<o + 1 * 128>(vx);
-    b[2] = lds_read<o + 2 * 128>(vx);
-    b[3] = lds_read<o + 3 * 128>(vx);
-}
-
-// wait until at most N LDS reads are outstanding; the "+v" ties make the fragments depend on it
-template <int N>
-__device__ __forceinline__ void lds_wait(double (&a)[4], double (&b)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(%8)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-                 : "n"(N));
-}
-
-__device__ __forceinline__ void mfma16(const double (&a)[4], const double (&b)[4], double4_t (&acc)[4][4]) {
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tj], b[ti], acc[ti][tj], 0, 0, 0);
-}
-
-__device__ __forceinline__ void compute_stage_asm(unsigned vx, unsigned vy, double4_t (&acc)[4][4]) {
-    double a0[4], b0[4], a1[4], b1[4];
-    read_frags<0>(vx, vy, a0, b0);
-    read_frags<1>(vx, vy, a1, b1);
-    lds_wait<8>(a0, b0);
-    mfma16(a0, b0, acc);
-    read_frags<2>(vx, vy, a0, b0);
-    lds_wait<8>(a1, b1);
-    mfma16(a1, b1, acc);
-    read_frags<3>(vx, vy, a1, b1);
-    lds_wait<8>(a0, b0);
-    mfma16(a0, b0, acc);
-    lds_wait<0>(a1, b1);
-    mfma16(a1, b1, acc);
-}
-
-// one LDS-DMA: 64 lanes x 16 B = one 1 KiB tile row; global address = scalar row pointer + lane*16
-__device__ __forceinline__ void dma_row(const double* row, unsigned lds_addr, unsigned voff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :
-                 : "s"(lds_addr), "v"(voff), "s"(row)
-                 : "memory");
-}
-
-// one stage of both operands into the buffer at scalar LDS address lds0 (X) / lds0 + Y_BYTES (Y):
-// wave w moves tile rows w, w+4, w+8, w+12
-__device__ __forceinline__ void dma_stage_asm(const double* xrow, const double* yrow, int64_t xstep,
-                                              int64_t ystep, unsigned lds0, unsigned voff) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        dma_row(xrow + r * xstep, lds0 + r * 4 * ROW_BYTES, voff);
-        dma_row(yrow + r * ystep, lds0 + Y_BYTES + r * 4 * ROW_BYTES, voff);
-    }
-}
-
-__device__ __forceinline__ void dma_join() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
-// interior tiles: global -> LDS directly; the DMA of stage s+1 is in flight while stage s computes
-__device__ __forceinline__ void mainloop_dma(const GemmArgs& g, int64_t i0, int64_t j0, double* lds,
-                                             int wi, int wj, int lane, int wave,
-                                             double4_t (&acc)[4][4]) {
-    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)lds;
-    const int nstage = __builtin_amdgcn_readfirstlane((int)(g.K / BK));  // scalar loop bound
-    // scalar pointers to tile row `wave` of the current stage; rows r*4 + wave are 4*ld apart
-    const double* xrow = g.X + (int64_t)wave * g.ldx + i0;
-    const double* yrow = g.Y + (int64_t)wave * g.ldy + j0;
-    const int64_t xstep = 4 * g.ldx, ystep = 4 * g.ldy;
-    const int64_t xadv = (int64_t)BK * g.ldx, yadv = (int64_t)BK * g.ldy;
-    const unsigned lds0 = lds_base + (unsigned)wave * ROW_BYTES;  // this wave's first row (scalar)
-    const unsigned voff = (unsigned)lane * 16;
-    // per-lane fragment bases: element (k = lane>>4, index = lane&15) of the wave's 64-wide strip
-    const unsigned rb = (unsigned)((lane >> 4) * ROW_BYTES + (lane & 15) * 8);
-    unsigned vx = lds_base + rb + (unsigned)wi * 512;
-    unsigned vy = lds_base + rb + (unsigned)wj * 512 + Y_BYTES;
-    if (nstage > 0) {
-        dma_stage_asm(xrow, yrow, xstep, ystep, lds0, voff);
-        xrow += xadv;
-        yrow += yadv;
-    }
-    dma_join();
-    int toggle = TILE_BYTES;  // scalar: +TILE_BYTES, -TILE_BYTES, ... (buffer of the NEXT stage)
-    unsigned fill = lds0 + TILE_BYTES;
-    for (int st = 0; st < nstage; ++st) {
-        if (st + 1 < nstage) {
-            dma_stage_asm(xrow, yrow, xstep, ystep, fill, voff);
-            xrow += xadv;
-            yrow += yadv;
-        }
-        compute_stage_asm(vx, vy, acc);
-        dma_join();
-        vx += toggle;  // the two VALU instructions of a stage
-        vy += toggle;
-        fill -= toggle;
-        toggle = -toggle;
-    }
-}
 
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_DOUBLES];

@@ -1,0 +1,40 @@
+// Diagnostic build of the fused mid-size factorisation step with phase stamps (never part of the product):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DMADQP_MID_STAMPS -x hip tools/mid_probe.cpp \
+//         madqp_jl_amd/csrc/{gemm_f64,ctx,gen}.hip -ldl -o tools/mid_probe
+// Prints, per block step k, the phases of the workgroup holding the diagonal tile and of workgroup 1;
+// s_memrealtime, 100 MHz.
+#include "../madqp_jl_amd/csrc/chol.hip"
+
+#include <cstdio>
+#include <vector>
+
+int main(int argc, char** argv) {
+    setenv("MADQP_CHOL_MID_MAX", "100000", 1);
+    madqp_ctx* ctx = nullptr;
+    if (madqp_ctx_create(0, nullptr, &ctx)) return 1;
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 2048, lda = (n + 127) / 128 * 128;
+    std::vector<double> h(lda * lda, 0.0);
+    for (int64_t j = 0; j < n; ++j)
+        for (int64_t i = j; i < n; ++i) h[i + j * lda] = (i == j) ? 2.0 * n : 1.0 / (1.0 + (double)((i * 7 + j * 13) % 17));
+    double* A;
+    (void)hipMalloc(&A, sizeof(double) * lda * lda);
+    madqp_chol* ch = nullptr;
+    if (madqp_chol_create(ctx, n, &ch)) return 1;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipMemcpy(A, h.data(), sizeof(double) * lda * lda, hipMemcpyHostToDevice);
+        int32_t info = -1;
+        if (madqp_chol_factor(ch, A, lda, &info)) return 1;
+        static unsigned long long st[64][16];
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(madqp_mid_stamps), sizeof(st));
+        if (rep < 2) continue;
+        const int nblk = (int)(lda / 128);
+        printf("info %d; per step: workgroup 0 [update, to LDS, factor + invert]; workgroup 1 [update, store]\n", info);
+        for (int k = 0; k < nblk && k < 64; ++k) {
+            auto us = [&](int a, int b) { return (double)(st[k][b] - st[k][a]) * 0.01; };
+            printf("k=%2d  diag %5.1f %5.1f %5.1f | other %5.1f", k, us(0, 1), us(1, 2), us(2, 3), us(8, 9));
+            if (k + 1 < nblk) printf(" | next step starts +%.1f after the diagonal workgroup ends", (double)(st[k + 1][0] - st[k][3]) * 0.01);
+            printf("\n");
+        }
+    }
+    return 0;
+}
