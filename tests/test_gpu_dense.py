@@ -108,12 +108,15 @@ def _spd(n, rng, cond=1e3):
     return (Qm * ev) @ Qm.T
 
 
-@pytest.mark.parametrize("n", [1, 2, 17, 128, 129, 255, 256, 400, 1024, 1100, 2300])
-def test_cholesky_factor_and_solve(hip, n):
+@pytest.mark.parametrize("n,padded", [(n, False) for n in [1, 2, 17, 128, 129, 255, 256, 400, 1024, 1100, 2300]]
+                         + [(n, True) for n in [129, 255, 300, 1024, 1100, 2300, 4100]])
+def test_cholesky_factor_and_solve(hip, n, padded):
+    """padded: the leading dimension covers the order rounded up to 128, as the KKT objects allocate K -- the
+    layout that takes the right-looking mid-size schedule (chol.hip, chol_mid_step_kernel) up to n = 12 288."""
     rng = np.random.default_rng(n)
     K = _spd(n, rng)
     K = 0.5 * (K + K.T)
-    lda = n + (3 if n % 2 else 2)
+    lda = (n + 127) // 128 * 128 + 2 if padded else n + (3 if n % 2 else 2)
     host = np.full((n, lda), np.nan)  # column-major lower: tensor row j = column j of K
     host[:, :n] = np.where(np.triu(np.ones((n, n))) > 0, K.T, np.nan)
     Kd = dev(host, hip)
