@@ -139,6 +139,10 @@ struct Potf2Batch {  // problem blockIdx.x: pointer strides (doubles / ints); sk
     int64_t sA, sW, sInfo;
     const int32_t* skip;
 };
+#ifndef P2_QUIET_WAVE
+#define P2_QUIET_WAVE 4
+#endif
+constexpr int P2_QUIET = P2_QUIET_WAVE;  // -1: every helper wave works in the trailing phase
 constexpr int P2_THREADS = 512;  // wave 0: the chain of 16 x 16 diagonal factorisations; waves 1..7: everything else
 // (1024 threads: loads and stores faster, the steps slower -- 45.2 vs 44.4 us)
 constexpr int P2_S_DOUBLES = NB * LDS_LD;         // S[c*LDS_LD + r] = element (r, c)
@@ -254,16 +258,20 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
             if (wave == 0) {
                 trailing_tile(J, J + 1, J + 1);
                 diag16_factor_invert(S, b + SB, WdJ + SB * WD_LD, info, col0, lane);
-            } else {
+            } else if (P2_QUIET < 0 || wave != P2_QUIET) {
+                // (wave P2_QUIET shares its SIMD with wave 0 and sits this phase out: the fp64 MFMAs of a helper
+                // there hold up every vector instruction of the pivot chain)
+                constexpr int NHE = (P2_QUIET < 0) ? NH : NH - 1;
+                const int hr = (P2_QUIET >= 0 && wave > P2_QUIET) ? wave - 2 : wave - 1;  // 0 .. NHE-1
                 int t = 0;
                 for (int K = J + 1; K < NSB; ++K)
                     for (int I = K; I < NSB; ++I) {
                         if (K == J + 1 && I == J + 1) continue;
-                        if ((t++ % NH) + 1 == wave) trailing_tile(J, K, I);
+                        if ((t++ % NHE) == hr) trailing_tile(J, K, I);
                     }
                 for (int I = J + 1; I < NSB; ++I)
                     for (int Jp = 0; Jp <= J; ++Jp)
-                        if ((t++ % NH) + 1 == wave) t_update(J, I, Jp);
+                        if ((t++ % NHE) == hr) t_update(J, I, Jp);
             }
         }
         __syncthreads();
@@ -966,9 +974,17 @@ extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int3
     const int64_t npad_m = (n + NB - 1) / NB * NB;
     if (n <= mid_max && n > NB && s->npos == n && lda >= npad_m && lda % 2 == 0 && (((uintptr_t)A) & 15) == 0) {
         const int32_t nblk = (int32_t)(npad_m / NB);
+        // one timer scope for the whole factorisation (80 short launches: a scope each costs 0.7 ms per factorisation
+        // at n = 5 000); the scopes of the launches inside are switched off meanwhile
+        ProfScope ps_all(ctx, MADQP_PROF_POTRF_GEMM);
+        struct ProfMute {
+            madqp_ctx* c;
+            decltype(c->prof) saved;
+            explicit ProfMute(madqp_ctx* ctx_) : c(ctx_), saved(ctx_->prof) { c->prof = 0; }
+            ~ProfMute() { c->prof = saved; }
+        } mute(ctx);
         for (int32_t k = 0; k < nblk; ++k) {
             {
-                ProfScope ps(ctx, MADQP_PROF_POTRF_GEMM);
                 const int64_t rem = nblk - k, ntiles = (k > 0) ? rem * (rem + 1) / 2 : 1;
                 const int32_t pack = (ntiles > ctx->gemm_slots / 2) ? 2 : 1;
                 const unsigned grid = (unsigned)(1 + (ntiles - 1 + pack - 1) / pack);
