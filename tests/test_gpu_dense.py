@@ -142,6 +142,44 @@ def test_cholesky_factor_and_solve(hip, n, padded):
         hip.chol_destroy(h)
 
 
+@pytest.mark.parametrize("n,chunk", [(1100, 2), (1100, 3), (2300, 5), (700, 1)])
+def test_sweeps_with_split_block_rows(hip, n, chunk):
+    """Block rows longer than MADQP_SWEEP_CHUNK tiles are streamed by several workgroups (chol.hip, SweepPlan; 64 tiles
+    by default, i.e. only beyond n = 8 320).  A small chunk puts the same code under a case the CPU can check: the
+    solution must agree with the one-job-per-row sweep to rounding (the partial sums are added in another order)."""
+    import os
+    rng = np.random.default_rng(n + chunk)
+    K = _spd(n, rng)
+    K = 0.5 * (K + K.T)
+    lda = n + 2
+    host = np.zeros((n, lda))
+    host[:, :n] = K.T
+    b = rng.standard_normal(n)
+    xs = []
+    for env in (str(chunk), None):
+        if env is None:
+            os.environ.pop("MADQP_SWEEP_CHUNK", None)
+        else:
+            os.environ["MADQP_SWEEP_CHUNK"] = env
+        try:
+            Kd = dev(host, hip)
+            h = hip.chol_create(n)  # the job list is built here
+        finally:
+            os.environ.pop("MADQP_SWEEP_CHUNK", None)
+        try:
+            assert hip.chol_factor(h, Kd, lda) == 0
+            bd = dev(b, hip)
+            hip.chol_solve(h, bd)
+            xs.append(bd.cpu().numpy())
+        finally:
+            hip.chol_destroy(h)
+    xref = sla.cho_solve((sla.cholesky(K, lower=True), True), b)
+    for x in xs:
+        assert np.linalg.norm(K @ x - b) / (np.linalg.norm(K) * np.linalg.norm(x)) < 1e-14
+        assert np.linalg.norm(x - xref) / np.linalg.norm(xref) < 1e-10
+    assert np.linalg.norm(xs[0] - xs[1]) / np.linalg.norm(xs[1]) < 1e-12
+
+
 def test_cholesky_not_positive_definite_reports_column(hip):
     """LAPACK info convention: first failing leading minor, never aborts (SURVEY 8b errors)."""
     n = 300
