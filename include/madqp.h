@@ -448,8 +448,16 @@ int32_t madqp_mpc_destroy(madqp_mpc* mpc);
 int32_t madqp_mpc_set_scalars(madqp_mpc* mpc, double mu, double del_w, double del_c, double obj, int64_t k);
 /* src/solver.jl:259-283; status_host: 0 continue, 1 SOLVE_SUCCEEDED, 6 MAXIMUM_ITERATIONS_EXCEEDED */
 int32_t madqp_mpc_head(madqp_mpc* mpc, madqp_mpc_info* info_host, int32_t* status_host);
-/* src/solver.jl:288-343; returns MADQP_NUM_NAN for MadNLP.SolveException (src/linear_solver.jl:41-43) */
+/* src/solver.jl:288-343; returns MADQP_NUM_NAN for MadNLP.SolveException (src/linear_solver.jl:41-43).
+ * Without Gondzio corrections, Mehrotra's adaptive step rule or refinement steps the reductions of an iteration are
+ * queued in the context's result block and read back three times per iteration (csrc/mpc.hip, body_fused; the
+ * iterates are bitwise those of the sequential form, which MADQP_MPC_FUSED=0 selects when the object is created);
+ * the residual norms of the next termination test come with the last of the three, so madqp_mpc_head behind a
+ * body does not synchronise at all. */
 int32_t madqp_mpc_body(madqp_mpc* mpc, madqp_mpc_info* info_host);
+/* blocking scalar read-backs issued so far by madqp_mpc_head / madqp_mpc_body of the fused form (the reference's loop
+ * has about 20 implicit synchronisations per iteration, src/solver.jl:264-343) */
+int32_t madqp_mpc_readbacks(const madqp_mpc* mpc, int64_t* count);
 
 /* ----------------------------------------- batches of small, equally shaped QPs */
 /* B problems with the same (nx, m) and the same bound / inequality pattern advance in lock step:

@@ -414,6 +414,12 @@ class HipBackend:
             self._ck(rc)
         return rc
 
+    def mpc_readbacks(self, h) -> int:
+        """Blocking scalar read-backs madqp_mpc_head / madqp_mpc_body have issued (the fused form counts them)."""
+        n = C.c_int64()
+        self._ck(self.lib.madqp_mpc_readbacks(h, C.byref(n)))
+        return n.value
+
     def kkt_matrix(self, h, nx):
         """Torch view (nx x ld, row = column of K) of the library-owned K for inspection."""
         p, ld = C.c_void_p(), C.c_int64()

@@ -952,19 +952,10 @@ static int32_t factor_range(madqp_chol* s, double* A, int64_t lda, int64_t j0, i
     return factor_range(s, A, lda, j0 + h, w - h);
 }
 
-extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int32_t* info_host) {
-    if (!s) return MADQP_ERR_ARG;
+// Everything of a factorisation except reading its info back: the launches are on the stream, info sits in s->d_info.
+static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
     madqp_ctx* ctx = s->ctx;
-    ARG_TRY(ctx, A && info_host && lda >= s->n);
     const int64_t n = s->n;
-    s->factored = false;
-    s->A = A;
-    s->lda = lda;
-    *info_host = 0;
-    if (n == 0) {
-        s->factored = true;
-        return MADQP_OK;
-    }
     HIP_TRY(ctx, hipMemsetAsync(s->d_info, 0, sizeof(int32_t), ctx->stream));
     // mid-size matrices: right-looking, two launches per 128-column block (chol_mid_step_kernel)
     // (measured on bench.py, m = 0.4 n: 1.55 against 1.78 ms per iteration at n = 1 000, 6.8 against 8.3 at 5 000,
@@ -1012,11 +1003,6 @@ extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int3
                 if (r) return r;
             }
         }
-        int32_t info_m = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&info_m, s->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        *info_host = info_m;
-        s->factored = (info_m == 0);
         return MADQP_OK;
     }
     // Quasi-definite mode (npos < n): A = [P, .; B, -Q] with P, Q positive definite and Q's block STORED AS +Q.
@@ -1039,12 +1025,58 @@ extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int3
         r = factor_range(s, A, lda, J0, W);
         if (r) return r;
     }
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int32_t* info_host) {
+    if (!s) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, A && info_host && lda >= s->n);
+    s->factored = false;
+    s->A = A;
+    s->lda = lda;
+    *info_host = 0;
+    if (s->n == 0) {
+        s->factored = true;
+        return MADQP_OK;
+    }
+    int32_t r = chol_factor_enqueue(s, A, lda);
+    if (r) return r;
     int32_t info = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&info, s->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *info_host = info;
     s->factored = (info == 0);
     return MADQP_OK;
+}
+
+namespace {
+__global__ void info_to_slot_kernel(const int32_t* __restrict__ info, double* __restrict__ slot) {
+    *slot = (double)*info;
+}
+}  // namespace
+// Queued form (mpc.hip): no read-back here; info goes to *d_slot (a word of the context's result block) and comes
+// back with the caller's next madqp_read_results, who then reports it through madqp_chol_factor_result.  Until then
+// the object counts as factored: solves enqueued behind a failed factorisation produce values the caller discards.
+int32_t madqp_chol_factor_q(madqp_chol* s, double* A, int64_t lda, double* d_slot) {
+    if (!s) return MADQP_ERR_ARG;
+    madqp_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, A && d_slot && lda >= s->n);
+    s->A = A;
+    s->lda = lda;
+    s->factored = true;
+    if (s->n == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(d_slot, 0, sizeof(double), ctx->stream));
+        return MADQP_OK;
+    }
+    int32_t r = chol_factor_enqueue(s, A, lda);
+    if (r) return r;
+    hipLaunchKernelGGL(info_to_slot_kernel, dim3(1), dim3(1), 0, ctx->stream, s->d_info, d_slot);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
+void madqp_chol_factor_result(madqp_chol* s, int32_t info) {
+    if (s) s->factored = (info == 0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -76,6 +76,20 @@ int32_t madqp_work_reserve(madqp_ctx* ctx, size_t bytes);
 void madqp_prof_begin(madqp_ctx* ctx, int cls);
 void madqp_prof_end(madqp_ctx* ctx);
 int32_t madqp_read_results(madqp_ctx* ctx, int count, double* out_host);
+// queued reductions (vec_kernels.hip, kkt.hip, chol.hip): results stay in ctx->d_res at the given slot until one
+// madqp_read_results fetches the block (slots 0 .. MADQP_FAULT_SLOT-1)
+int32_t madqp_q_compl(madqp_ctx* ctx, const madqp_state* st, int affine, double ap, double ad, const double* a8,
+                      int slot0);                                                               // 2 slots: sums
+int32_t madqp_q_alpha_max(madqp_ctx* ctx, const madqp_state* st, double tau, int slot0);        // 8 slots
+int32_t madqp_q_inf(madqp_ctx* ctx, const madqp_state* st, int slot0);                          // 4 slots
+void madqp_inf_from_block(const double* out4, double* out3);
+int32_t madqp_q_norm_inf3(madqp_ctx* ctx, int64_t len, const double* a, const double* b, const double* c,
+                          int slot0);                                                           // 3 slots
+int32_t madqp_q_kkt_eval(madqp_kkt* k, const madqp_state* st, const double* q, const double* rhs, int slot0);  // 2
+int32_t madqp_q_kkt_factorize(madqp_kkt* k, int slot0);                                         // 1 slot: info
+int32_t madqp_kkt_factor_result(madqp_kkt* k, int32_t info);
+int32_t madqp_chol_factor_q(madqp_chol* s, double* A, int64_t lda, double* d_slot);  // info -> *d_slot, no read-back
+void madqp_chol_factor_result(madqp_chol* s, int32_t info);                           // what the read-back said
 
 struct ProfScope {
     madqp_ctx* c;

@@ -549,6 +549,17 @@ extern "C" int32_t madqp_kkt_factorize(madqp_kkt* k, int32_t* info_host) {
     if (!k) return MADQP_ERR_ARG;
     return madqp_chol_factor(k->chol, k->K, k->ldk, info_host);
 }
+// queued form: the factorisation is enqueued, its info lands in the result block; madqp_kkt_factor_result hands the
+// value the caller read back to the solver object
+int32_t madqp_q_kkt_factorize(madqp_kkt* k, int slot0) {
+    if (!k) return MADQP_ERR_ARG;
+    return madqp_chol_factor_q(k->chol, k->K, k->ldk, k->ctx->d_res + slot0);
+}
+int32_t madqp_kkt_factor_result(madqp_kkt* k, int32_t info) {
+    if (!k) return MADQP_ERR_ARG;
+    madqp_chol_factor_result(k->chol, info);
+    return MADQP_OK;
+}
 
 extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* w) {
     int32_t r = check_kkt_state(k, st);
@@ -670,12 +681,12 @@ extern "C" int32_t madqp_kkt_mul(madqp_kkt* k, const madqp_state* st, double* w,
     return madqp_kktmul(ctx, st, w, v, alpha, beta);
 }
 
-extern "C" int32_t madqp_kkt_eval(madqp_kkt* k, const madqp_state* st, const double* q,
-                                  const double* rhs, double c0, double* obj_host) {
+// objective pieces into 2 slots (q'x and x'Hx; obj = c0 + s0 + s1/2), gradient and constraint values into st
+int32_t madqp_q_kkt_eval(madqp_kkt* k, const madqp_state* st, const double* q, const double* rhs, int slot0) {
     int32_t r = check_kkt_state(k, st);
     if (r) return r;
     madqp_ctx* ctx = k->ctx;
-    ARG_TRY(ctx, obj_host && (k->nx == 0 || q) && (k->m == 0 || rhs));
+    ARG_TRY(ctx, (k->nx == 0 || q) && (k->m == 0 || rhs));
     const int64_t nx = k->nx, n = st->n;
     if (k->H && nx)
         if ((r = madqp_gemv_impl(ctx, 0, nx, nx, 1.0, k->H, k->ldh, st->x, 0.0, st->f, MADQP_PROF_GEMV)))
@@ -684,7 +695,6 @@ extern "C" int32_t madqp_kkt_eval(madqp_kkt* k, const madqp_state* st, const dou
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(hdiag_mul_kernel, nx, nx, k->hdiag, st->x, st->f);
     }
-    double sums[2] = {0.0, 0.0};
     if (n) {
         const int nb = grid_for(n);
         {
@@ -693,20 +703,28 @@ extern "C" int32_t madqp_kkt_eval(madqp_kkt* k, const madqp_state* st, const dou
                                ((k->H || k->hdiag) && nx) ? 1 : 0, q, st->x, st->f, ctx->d_part);
             LAUNCH_CHECK(ctx);
             hipLaunchKernelGGL(sum2_final_kernel, dim3(1), dim3(TPB), 0, ctx->stream, ctx->d_part, nb,
-                               ctx->d_res);
+                               ctx->d_res + slot0);
             LAUNCH_CHECK(ctx);
         }
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res + slot0, 0, 2 * sizeof(double), ctx->stream));
     }
     if (k->m) {
         if ((r = apply_A(k, 1.0, st->x, 0.0, st->c))) return r;
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(eval_cons_kernel, k->m, k->m, k->d_slot, st->x + nx, rhs, st->c);
     }
-    if (n) {
-        if ((r = madqp_read_results(ctx, 2, sums))) return r;
-    } else {
-        if ((r = madqp_ctx_sync(ctx))) return r;
-    }
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_kkt_eval(madqp_kkt* k, const madqp_state* st, const double* q,
+                                  const double* rhs, double c0, double* obj_host) {
+    if (!k) return MADQP_ERR_ARG;
+    ARG_TRY(k->ctx, obj_host != nullptr);
+    int32_t r = madqp_q_kkt_eval(k, st, q, rhs, 0);
+    if (r) return r;
+    double sums[2] = {0.0, 0.0};
+    if ((r = madqp_read_results(k->ctx, 2, sums))) return r;
     *obj_host = c0 + sums[0] + 0.5 * sums[1];
     return MADQP_OK;
 }

@@ -3,9 +3,23 @@
 // The same control flow as madqp_jl_amd/solver.py (MPCSolver.iteration_head / iteration_body), in
 // C++ above the kernels of this library: one foreign call per iteration instead of ~60, so the host
 // overhead of an interpreted driver disappears (it matters for small problems and for batches,
-// where each host thread drives its own context).  Scalars still come back per reduction; the
-// fully device-resident variant is listed as next in DESIGN.md.
+// where each host thread drives its own context).
+//
+// Blocking read-backs.  The sequential form (body_sequential: every reduction returns its scalar at once) makes about
+// ten per iteration.  The fused form (body_fused; AdaptiveStep / ConservativeStep without Gondzio corrections, which
+// is what the iteration count of a correction depends on) queues the reductions of a phase in the context's result
+// block and reads the block THREE times per iteration:
+//   (a) after the predictor: factorisation info, residual norms of solve_system!, the four step-length minima,
+//       the affine complementarity sums (whose kernel takes the step lengths from the block, not from the host)
+//       and the complementarity sums  -> sigma, mu on the host, in the arithmetic of the sequential form;
+//   (b) after the corrector: residual norms, step-length minima, |dx|  -> SolveException test BEFORE the iterates move;
+//   (c) after the update: objective sums and the residual norms of the NEXT termination test (madqp_mpc_head then
+//       finds them cached).
+// Same kernels, same host arithmetic, same order on the stream: the iterates are bitwise those of the sequential
+// form (tests/test_gpu_solver.py).  A failed first factorisation (the x100 retries of src/linear_solver.jl:6-17)
+// sends the rest of that iteration down the sequential form.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -22,6 +36,10 @@ struct madqp_mpc {
     double reg_delta_p, reg_delta_d;  // AdaptiveRegularization state (src/kernels.jl:410-417)
     int64_t k, n_factorizations;
     int32_t last_info;
+    bool fused;        // body_fused eligible (options) and not switched off (MADQP_MPC_FUSED=0)
+    bool head_cached;  // nrm_cached = the residual norms of the current iterate, read with the last body's block (c)
+    double nrm_cached[3];
+    int64_t n_readbacks;  // blocking scalar read-backs issued by head/body (reported for DESIGN's count)
 };
 
 madqp_ctx* madqp_kkt_ctx(madqp_kkt* kkt);  // kkt.hip
@@ -55,8 +73,8 @@ void update_regularization(madqp_mpc* s) {
 }
 
 // src/linear_solver.jl:6-17
-int32_t factorize_regularized_system(madqp_mpc* s) {
-    for (int trial = 0; trial < 3; ++trial) {
+int32_t factorize_regularized_system(madqp_mpc* s, int first_trial = 0) {
+    for (int trial = first_trial; trial < 3; ++trial) {
         TRY(madqp_kkt_set_aug_diagonal_reg(s->kkt, &s->st, s->del_w, s->del_c));  // dispatched on the KKT type
         TRY(madqp_kkt_build(s->kkt, &s->st));
         TRY(madqp_kkt_factorize(s->kkt, &s->last_info));
@@ -256,6 +274,8 @@ extern "C" int32_t madqp_mpc_create(madqp_kkt* kkt, const madqp_state* st, doubl
     s->opt = *opt;
     s->reg_delta_p = opt->delta_p;
     s->reg_delta_d = opt->delta_d;
+    const char* env = getenv("MADQP_MPC_FUSED");  // 0: the sequential form (A/B tests)
+    s->fused = !(env && env[0] == '0') && opt->max_ncorr == 0 && opt->step_rule != 2 && opt->refine_steps == 0;
     *out = s;
     return MADQP_OK;
 }
@@ -273,6 +293,7 @@ extern "C" int32_t madqp_mpc_set_scalars(madqp_mpc* s, double mu, double del_w, 
     s->del_c = del_c;
     s->obj = obj;
     s->k = k;
+    s->head_cached = false;
     return MADQP_OK;
 }
 
@@ -280,9 +301,14 @@ extern "C" int32_t madqp_mpc_set_scalars(madqp_mpc* s, double mu, double del_w, 
 // status_host: 0 = continue, 1 = SOLVE_SUCCEEDED, 6 = MAXIMUM_ITERATIONS_EXCEEDED
 extern "C" int32_t madqp_mpc_head(madqp_mpc* s, madqp_mpc_info* info_host, int32_t* status_host) {
     if (!s || !status_host) return MADQP_ERR_ARG;
-    TRY(madqp_kkt_jtprod(s->kkt, s->st.jacl, s->st.y));
     double nrm[3];
-    TRY(madqp_get_inf(s->ctx, &s->st, nrm));
+    if (s->head_cached) {  // read with the last body's block (c): same iterate, same kernels
+        for (int q = 0; q < 3; ++q) nrm[q] = s->nrm_cached[q];
+    } else {
+        TRY(madqp_kkt_jtprod(s->kkt, s->st.jacl, s->st.y));
+        TRY(madqp_get_inf(s->ctx, &s->st, nrm));
+        s->n_readbacks += 1;
+    }
     s->inf_pr = nrm[0] / std::max(1.0, s->norm_b);
     s->inf_du = nrm[1] / std::max(1.0, s->norm_c);
     s->inf_compl = nrm[2] / std::max(1.0, s->norm_c);
@@ -296,13 +322,10 @@ extern "C" int32_t madqp_mpc_head(madqp_mpc* s, madqp_mpc_info* info_host, int32
     return MADQP_OK;
 }
 
-// src/solver.jl:288-343: one predictor-corrector step.  Returns MADQP_NUM_NAN for the
-// SolveException of src/linear_solver.jl:41-43.
-extern "C" int32_t madqp_mpc_body(madqp_mpc* s, madqp_mpc_info* info_host) {
-    if (!s) return MADQP_ERR_ARG;
+namespace {
+// src/solver.jl:294-343 behind a successful factorisation, every reduction read back at once
+int32_t body_after_factorization(madqp_mpc* s, madqp_mpc_info* info_host) {
     madqp_ctx* ctx = s->ctx;
-    update_regularization(s);                   // :288
-    TRY(factorize_regularized_system(s));       // :289
     TRY(madqp_set_predictive_rhs(ctx, &s->st)); // :294
     TRY(solve_system(s));
     double a_aff_p, a_aff_d, mu_affine, mu_curr;
@@ -334,5 +357,107 @@ extern "C" int32_t madqp_mpc_body(madqp_mpc* s, madqp_mpc_info* info_host) {
     TRY(madqp_adjust_boundary(ctx, &s->st, s->mu));                    // :342
     s->k += 1;
     fill_info(s, info_host);
+    return MADQP_OK;
+}
+
+int32_t body_sequential(madqp_mpc* s, madqp_mpc_info* info_host) {
+    update_regularization(s);                   // :288
+    TRY(factorize_regularized_system(s));       // :289
+    return body_after_factorization(s, info_host);
+}
+
+// solve_system! up to its reduction: d = K^-1 p, w1 = p - K d, the three norms into the result block at slot0
+int32_t solve_system_queue(madqp_mpc* s, int slot0) {
+    const int64_t len = ntot(s->st);
+    TRY(madqp_copy(s->ctx, len, s->st.p, s->st.d));
+    TRY(madqp_kkt_solve(s->kkt, &s->st, s->st.d));
+    TRY(madqp_copy(s->ctx, len, s->st.p, s->w1));
+    TRY(madqp_kkt_mul(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));
+    return madqp_q_norm_inf3(s->ctx, len, s->w1, s->st.p, s->st.d, slot0);
+}
+int32_t residual_verdict(madqp_mpc* s, const double* nrm) {  // src/linear_solver.jl:36-43
+    const double ratio = nrm[0] / std::max(1.0, nrm[1]);
+    s->residual_ratio = ratio;
+    if (std::isnan(ratio) || (s->opt.check_residual && ratio > s->opt.tol_linear_solve)) return MADQP_NUM_NAN;
+    return MADQP_OK;
+}
+inline double min_like_host(double a, double b) { return std::min(a, b); }  // fraction_to_boundary's combination
+
+// The same iteration with three blocking read-backs (see the head of this file).
+int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
+    madqp_ctx* ctx = s->ctx;
+    const int64_t nb = s->st.nlb + s->st.nub;
+    double r[16];
+    update_regularization(s);  // :288
+    // (a) factorisation and predictor
+    TRY(madqp_kkt_set_aug_diagonal_reg(s->kkt, &s->st, s->del_w, s->del_c));
+    TRY(madqp_kkt_build(s->kkt, &s->st));
+    TRY(madqp_q_kkt_factorize(s->kkt, 15));
+    s->n_factorizations += 1;
+    TRY(madqp_set_predictive_rhs(ctx, &s->st));                                  // :294
+    TRY(solve_system_queue(s, 0));
+    TRY(madqp_q_alpha_max(ctx, &s->st, 1.0, 3));                                 // :295
+    TRY(madqp_q_compl(ctx, &s->st, 1, 0.0, 0.0, ctx->d_res + 3, 11));            // :296, step lengths from the block
+    TRY(madqp_get_correction(ctx, &s->st));                                      // :297
+    TRY(madqp_q_compl(ctx, &s->st, 0, 0.0, 0.0, nullptr, 13));
+    TRY(madqp_read_results(ctx, 16, r));
+    s->n_readbacks += 1;
+    s->last_info = (int32_t)r[15];
+    TRY(madqp_kkt_factor_result(s->kkt, s->last_info));
+    if (s->last_info != 0) {  // src/linear_solver.jl:6-17: what was queued behind the failed factorisation is void
+        s->del_w *= 100.0;
+        s->del_c *= 100.0;
+        TRY(factorize_regularized_system(s, 1));
+        return body_after_factorization(s, info_host);
+    }
+    TRY(residual_verdict(s, r));
+    const double mu_affine = nb ? (r[11] + r[12]) / (double)nb : 0.0;
+    const double mu_curr = nb ? (r[13] + r[14]) / (double)nb : 0.0;
+    double sigma = 1.0;
+    if (nb > 0) {
+        const double t = mu_affine / mu_curr;
+        sigma = std::min(std::max(std::pow(t, 3.0), 1e-6), 10.0);
+    }
+    s->mu = std::max(s->opt.mu_min, sigma * mu_curr);
+    // (b) corrector
+    TRY(madqp_set_correction_rhs(ctx, &s->st, s->mu));  // :307
+    TRY(solve_system_queue(s, 0));
+    const double tau = (s->opt.step_rule == 0) ? s->opt.step_param : std::max(1.0 - s->mu, s->opt.step_param);
+    TRY(madqp_q_alpha_max(ctx, &s->st, tau, 3));
+    TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, 11));  // print_iter, src/structure.jl:190
+    TRY(madqp_read_results(ctx, 14, r));
+    s->n_readbacks += 1;
+    TRY(residual_verdict(s, r));
+    s->alpha_p = min_like_host(r[3], r[5]);
+    s->alpha_d = min_like_host(r[7], r[9]);
+    s->dnorm = r[11];
+    // (c) update, objective, and the residuals the next termination test needs
+    TRY(madqp_update_iterates(ctx, &s->st, s->alpha_p, s->alpha_d));  // :332-335
+    TRY(madqp_q_kkt_eval(s->kkt, &s->st, s->q, s->rhs, 0));           // :338-340
+    TRY(madqp_adjust_boundary(ctx, &s->st, s->mu));                   // :342
+    s->k += 1;
+    TRY(madqp_kkt_jtprod(s->kkt, s->st.jacl, s->st.y));               // :259-283 of the next pass
+    TRY(madqp_q_inf(ctx, &s->st, 2));
+    TRY(madqp_read_results(ctx, 6, r));
+    s->n_readbacks += 1;
+    s->obj = s->c0 + r[0] + 0.5 * r[1];
+    madqp_inf_from_block(r + 2, s->nrm_cached);
+    s->head_cached = true;
+    fill_info(s, info_host);
+    return MADQP_OK;
+}
+}  // namespace
+
+// src/solver.jl:288-343: one predictor-corrector step.  Returns MADQP_NUM_NAN for the
+// SolveException of src/linear_solver.jl:41-43.
+extern "C" int32_t madqp_mpc_body(madqp_mpc* s, madqp_mpc_info* info_host) {
+    if (!s) return MADQP_ERR_ARG;
+    s->head_cached = false;
+    return s->fused ? body_fused(s, info_host) : body_sequential(s, info_host);
+}
+
+extern "C" int32_t madqp_mpc_readbacks(const madqp_mpc* s, int64_t* count) {
+    if (!s || !count) return MADQP_ERR_ARG;
+    *count = s->n_readbacks;
     return MADQP_OK;
 }

@@ -25,12 +25,12 @@ inline int grid_for(int64_t len) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((len + TPB - 1) / TPB, MADQP_MAX_BLOCKS));
 }
 
-int32_t finalize(madqp_ctx* ctx, int nblocks, int nv, const int* ops) {
+int32_t finalize(madqp_ctx* ctx, int nblocks, int nv, const int* ops, int slot0 = 0) {
     FinalOps f;
     f.nv = nv;
     for (int i = 0; i < nv; ++i) f.op[i] = (int8_t)ops[i];
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(TPB), 0, ctx->stream, ctx->d_part, nblocks, f,
-                       ctx->d_res);
+                       ctx->d_res + slot0);
     LAUNCH_CHECK(ctx);
     return MADQP_OK;
 }
@@ -107,6 +107,25 @@ extern "C" int32_t madqp_set_extra_correction(madqp_ctx* ctx, const madqp_state*
     return MADQP_OK;
 }
 
+// Queued forms (madqp_q_*): the reduction lands in the device result block at slot0 and stays there; the caller
+// reads several of them back with ONE madqp_read_results (mpc.hip).  The extern "C" entry points below are the
+// queued form at slot 0 followed by the read-back.
+int32_t madqp_q_compl(madqp_ctx* ctx, const madqp_state* st, int affine, double ap, double ad, const double* a8,
+                      int slot0) {
+    CHECK_STATE();
+    if (st->nlb + st->nub == 0) {  // src/kernels.jl:173-174
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res + slot0, 0, 2 * sizeof(double), ctx->stream));
+        return MADQP_OK;
+    }
+    const int64_t L = std::max(st->nlb, st->nub);
+    const int nb = grid_for(L);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    hipLaunchKernelGGL(compl_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, *st, affine, ap, ad, a8, ctx->d_part);
+    LAUNCH_CHECK(ctx);
+    const int ops[2] = {OP_SUM, OP_SUM};
+    return finalize(ctx, nb, 2, ops, slot0);
+}
+
 static int32_t compl_launch(madqp_ctx* ctx, const madqp_state* st, int affine, double ap, double ad,
                             double* mu_host) {
     CHECK_STATE();
@@ -115,19 +134,10 @@ static int32_t compl_launch(madqp_ctx* ctx, const madqp_state* st, int affine, d
         *mu_host = 0.0;
         return MADQP_OK;
     }
-    const int64_t L = std::max(st->nlb, st->nub);
-    const int nb = grid_for(L);
-    {
-        ProfScope ps(ctx, MADQP_PROF_VEC);
-        hipLaunchKernelGGL(compl_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, *st, affine, ap, ad,
-                           ctx->d_part);
-        LAUNCH_CHECK(ctx);
-        const int ops[2] = {OP_SUM, OP_SUM};
-        int32_t r = finalize(ctx, nb, 2, ops);
-        if (r) return r;
-    }
+    int32_t r = madqp_q_compl(ctx, st, affine, ap, ad, nullptr, 0);
+    if (r) return r;
     double out[2];
-    int32_t r = madqp_read_results(ctx, 2, out);
+    r = madqp_read_results(ctx, 2, out);
     if (r) return r;
     *mu_host = (out[0] + out[1]) / (double)(st->nlb + st->nub);
     return MADQP_OK;
@@ -142,6 +152,32 @@ extern "C" int32_t madqp_get_affine_complementarity_measure(madqp_ctx* ctx, cons
     return compl_launch(ctx, st, 1, alpha_p, alpha_d, mu_host);
 }
 
+namespace {
+__global__ void alpha_none_kernel(double* __restrict__ res) {  // no bounds: alpha = 1, nothing blocks
+    if (threadIdx.x < 4) {
+        res[2 * threadIdx.x] = 1.0;
+        res[2 * threadIdx.x + 1] = -1.0;
+    }
+}
+}  // namespace
+int32_t madqp_q_alpha_max(madqp_ctx* ctx, const madqp_state* st, double tau, int slot0) {
+    CHECK_STATE();
+    const int64_t L = std::max(st->nlb, st->nub);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    if (L == 0) {
+        hipLaunchKernelGGL(alpha_none_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_res + slot0);
+        LAUNCH_CHECK(ctx);
+        return MADQP_OK;
+    }
+    const int nb = grid_for(L);
+    hipLaunchKernelGGL(alpha_max_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, *st, tau, ctx->d_part);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(alpha_max_final_kernel, dim3(1), dim3(TPB), 0, ctx->stream, ctx->d_part, nb,
+                       ctx->d_res + slot0);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
+
 extern "C" int32_t madqp_get_alpha_max(madqp_ctx* ctx, const madqp_state* st, double tau,
                                        double* alpha_host, int64_t* iblock_host) {
     CHECK_STATE();
@@ -154,18 +190,10 @@ extern "C" int32_t madqp_get_alpha_max(madqp_ctx* ctx, const madqp_state* st, do
         }
         return MADQP_OK;
     }
-    const int nb = grid_for(L);
-    {
-        ProfScope ps(ctx, MADQP_PROF_VEC);
-        hipLaunchKernelGGL(alpha_max_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, *st, tau,
-                           ctx->d_part);
-        LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(alpha_max_final_kernel, dim3(1), dim3(TPB), 0, ctx->stream, ctx->d_part,
-                           nb, ctx->d_res);
-        LAUNCH_CHECK(ctx);
-    }
+    int32_t r = madqp_q_alpha_max(ctx, st, tau, 0);
+    if (r) return r;
     double out[8];
-    int32_t r = madqp_read_results(ctx, 8, out);
+    r = madqp_read_results(ctx, 8, out);
     if (r) return r;
     for (int q = 0; q < 4; ++q) {
         alpha_host[q] = out[2 * q];
@@ -181,6 +209,26 @@ extern "C" int32_t madqp_update_iterates(madqp_ctx* ctx, const madqp_state* st, 
     LAUNCH(update_iterates_kernel, max4(st->n, st->m, st->nlb, st->nub), *st, alpha_p, alpha_d);
     return MADQP_OK;
 }
+// 4 slots: |c|, dual, complementarity lower / upper (madqp_inf_from_block combines the last two)
+int32_t madqp_q_inf(madqp_ctx* ctx, const madqp_state* st, int slot0) {
+    CHECK_STATE();
+    const int64_t L = max4(st->n, st->m, st->nlb, st->nub);
+    if (L == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res + slot0, 0, 4 * sizeof(double), ctx->stream));
+        return MADQP_OK;
+    }
+    const int nb = grid_for(L);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    hipLaunchKernelGGL(inf_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, *st, ctx->d_part);
+    LAUNCH_CHECK(ctx);
+    const int ops[4] = {OP_MAX, OP_MAX, OP_MAX, OP_MAX};
+    return finalize(ctx, nb, 4, ops, slot0);
+}
+void madqp_inf_from_block(const double* out, double* out3) {
+    out3[0] = out[0];
+    out3[1] = out[1];
+    out3[2] = (out[2] != out[2]) ? out[2] : ((out[3] != out[3]) ? out[3] : std::max(out[2], out[3]));
+}
 
 extern "C" int32_t madqp_get_inf(madqp_ctx* ctx, const madqp_state* st, double* out_host) {
     CHECK_STATE();
@@ -190,21 +238,12 @@ extern "C" int32_t madqp_get_inf(madqp_ctx* ctx, const madqp_state* st, double* 
         out_host[0] = out_host[1] = out_host[2] = 0.0;
         return MADQP_OK;
     }
-    const int nb = grid_for(L);
-    {
-        ProfScope ps(ctx, MADQP_PROF_VEC);
-        hipLaunchKernelGGL(inf_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, *st, ctx->d_part);
-        LAUNCH_CHECK(ctx);
-        const int ops[4] = {OP_MAX, OP_MAX, OP_MAX, OP_MAX};
-        int32_t r = finalize(ctx, nb, 4, ops);
-        if (r) return r;
-    }
-    double out[4];
-    int32_t r = madqp_read_results(ctx, 4, out);
+    int32_t r = madqp_q_inf(ctx, st, 0);
     if (r) return r;
-    out_host[0] = out[0];
-    out_host[1] = out[1];
-    out_host[2] = (out[2] != out[2]) ? out[2] : ((out[3] != out[3]) ? out[3] : std::max(out[2], out[3]));
+    double out[4];
+    r = madqp_read_results(ctx, 4, out);
+    if (r) return r;
+    madqp_inf_from_block(out, out_host);
     return MADQP_OK;
 }
 
@@ -252,6 +291,22 @@ extern "C" int32_t madqp_kktmul(madqp_ctx* ctx, const madqp_state* st, double* w
     return MADQP_OK;
 }
 
+int32_t madqp_q_norm_inf3(madqp_ctx* ctx, int64_t len, const double* a, const double* b, const double* c,
+                          int slot0) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, len >= 0);
+    if (len == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res + slot0, 0, 3 * sizeof(double), ctx->stream));
+        return MADQP_OK;
+    }
+    const int nb = grid_for(len);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    hipLaunchKernelGGL(norm_inf3_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, len, a, b, c, ctx->d_part);
+    LAUNCH_CHECK(ctx);
+    const int ops[3] = {OP_MAX, OP_MAX, OP_MAX};
+    return finalize(ctx, nb, 3, ops, slot0);
+}
+
 extern "C" int32_t madqp_norm_inf3(madqp_ctx* ctx, int64_t len, const double* a, const double* b,
                                    const double* c, double* out_host) {
     if (!ctx) return MADQP_ERR_ARG;
@@ -260,16 +315,8 @@ extern "C" int32_t madqp_norm_inf3(madqp_ctx* ctx, int64_t len, const double* a,
         out_host[0] = out_host[1] = out_host[2] = 0.0;
         return MADQP_OK;
     }
-    const int nb = grid_for(len);
-    {
-        ProfScope ps(ctx, MADQP_PROF_VEC);
-        hipLaunchKernelGGL(norm_inf3_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, len, a, b, c,
-                           ctx->d_part);
-        LAUNCH_CHECK(ctx);
-        const int ops[3] = {OP_MAX, OP_MAX, OP_MAX};
-        int32_t r = finalize(ctx, nb, 3, ops);
-        if (r) return r;
-    }
+    int32_t r = madqp_q_norm_inf3(ctx, len, a, b, c, 0);
+    if (r) return r;
     return madqp_read_results(ctx, 3, out_host);
 }
 

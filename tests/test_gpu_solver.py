@@ -320,6 +320,45 @@ def test_native_driver_is_bitwise_the_python_driver(hip):
         s.close()
 
 
+def test_fused_iteration_is_bitwise_the_sequential_one_with_three_readbacks(hip):
+    """csrc/mpc.hip, body_fused: the reductions of an iteration are queued in the result block and read back three
+    times (predictor, corrector, update + the next termination test) instead of once per reduction; kernels, host
+    arithmetic and stream order are those of the sequential form, so traces and iterates agree bit for bit -- also
+    when the first factorisation of an iteration fails and the x100 retry takes over."""
+    import os
+
+    def run(qp, fused, **kw):
+        os.environ["MADQP_MPC_FUSED"] = "1" if fused else "0"
+        try:
+            s = M.MPCSolver(to_device(qp, hip), hip, driver="native", **kw)  # the switch is read when the loop object
+            r = s.solve()                                                    # is created (initialize)
+            r["readbacks"] = hip.mpc_readbacks(s._native)
+            s.close()
+        finally:
+            os.environ.pop("MADQP_MPC_FUSED", None)
+        return r
+
+    retry_qp, free = Q.synthetic_qp(8, 20, 8), 3
+    retry_qp.lvar[free], retry_qp.uvar[free] = -np.inf, np.inf
+    retry_qp.H = np.diag(np.diag(retry_qp.H))
+    retry_qp.A[:, free] = 0.0
+    retry_qp.H[free, free] = -1e-7
+    retry_qp.q[free] = 0.0
+    cases = ((Q.synthetic_qp(77, 200, 80), dict(regularization=M.FixedRegularization(1e-8, -1e-8)), True),
+             (Q.synthetic_qp(78, 120, 50, "lp"), dict(regularization=M.AdaptiveRegularization(1e-8, -1e-9, 1e-9)), True),
+             (Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)),
+              dict(regularization=M.FixedRegularization(1e-8, -1e-8), step_rule=M.ConservativeStep(0.99)), True),
+             (retry_qp, dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_iter=4), False))
+    for qp, kw, converges in cases:
+        a, b = run(qp, False, **kw), run(qp, True, **kw)
+        assert a["status"] == b["status"] and a["iter"] == b["iter"]
+        assert (a["status"] == M.SOLVE_SUCCEEDED) == converges
+        assert a["trace"] == b["trace"] and a["n_factorizations"] == b["n_factorizations"]
+        assert np.array_equal(a["solution"], b["solution"]) and a["objective"] == b["objective"]
+        if converges:  # one read-back for the first termination test, three per iteration after that
+            assert b["readbacks"] == 1 + 3 * b["iter"], (b["readbacks"], b["iter"])
+
+
 def test_batch_of_independent_qps(hip):
     """BASELINE configs[3] in miniature: a batch of independent QPs solved with several contexts /
     streams in flight gives, problem by problem, the oracle's result (status, iterations, solution)."""
