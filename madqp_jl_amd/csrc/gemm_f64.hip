@@ -129,9 +129,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
                     W[(wj * 64 + tj * 16 + hi + 4 * v) * BM + wi * 64 + ti * 16 + lo] = acc[ti][tj][v];
         return;
     }
+    // out = alpha*acc + beta*Cin (+ dvec on the diagonal).  The addend is fetched 16 elements at a time from clamped
+    // (always valid) addresses BEFORE the guarded stores: as one guarded read-modify-write per element the compiler
+    // emits load, s_waitcnt vmcnt(0), store -- 64 dependent round trips, 40-45 us per tile, which is what held the
+    // K = 128 .. 1024 update launches of the factorisation at 15-59 TFLOP/s.  Same arithmetic, same results.
+    const bool has_cin = (g.Cin != nullptr);
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
         const int64_t gi = i0 + wi * 64 + ti * 16 + lo;
+        double cin[4][4];
+        if (has_cin) {
+            const int64_t gic = gi < g.M ? gi : g.M - 1;
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t gj = j0 + wj * 64 + tj * 16 + hi + 4 * v;
+                    cin[tj][v] = g.Cin[gic + (gj < g.N ? gj : g.N - 1) * g.ldcin];
+                }
+        }
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
 #pragma unroll
@@ -139,11 +155,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
                 const int64_t gj = j0 + wj * 64 + tj * 16 + hi + 4 * v;
                 if (gi < g.M && gj < g.N && (!g.lower_only || gi + g.diag_off >= gj)) {
                     double val = g.alpha * acc[ti][tj][v];
-                    if (g.Cin) val += g.beta * g.Cin[gi + gj * g.ldcin];
-                    if (g.dvec && gi + g.diag_off == gj) val += g.dvec[gj];
+                    if (has_cin) val += g.beta * cin[tj][v];
                     g.C[gi + gj * g.ldc] = val;
                 }
             }
+        }
+    }
+    // + dvec where global row == global column: a second pass over the (at most 128) diagonal elements of the tile,
+    // after the stores above are visible to the workgroup -- val + dvec[j] either way
+    if (g.dvec) {
+        __syncthreads();
+        if (tid < BN) {
+            const int64_t gj = j0 + tid, gi = gj - g.diag_off;
+            if (gj < g.N && gi >= i0 && gi < i0 + BM && gi < g.M) g.C[gi + gj * g.ldc] += g.dvec[gj];
         }
     }
 }
