@@ -14,7 +14,7 @@ def outer_w(rows, has_update, slots=512):
     if not has_update or mt <= 6:
         return 1024
     best, best_eff = 8, -1.0
-    for wt in range(6, min(16, mt) + 1):
+    for wt in range(6, min(20, mt) + 1):  # MADQP_CHOL_WMIN / WMAX defaults of chol.hip
         tiles = mt * wt - wt * (wt - 1) // 2
         rounds = (tiles + slots - 1) // slots
         eff = tiles / (rounds * slots)
