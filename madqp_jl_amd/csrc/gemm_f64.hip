@@ -181,33 +181,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, const in
     const int64_t i0 = (int64_t)(packed >> 16) * BM, j0 = (int64_t)(packed & 0xFFFF) * BN;
     const int li = threadIdx.x & (BM - 1);
     const int64_t gi = i0 + li;
-    // eight columns per pass with all their loads issued before the first store (Cin may alias C, so the compiler
-    // cannot hoist them itself): one dependent load per column made this kernel 60-80 us for a hundred tiles
+    // eight columns per pass with all their loads issued before the first store, every load unconditional (clamped
+    // addresses; the partial tiles are whole): a load under a condition is followed by its own s_waitcnt -- one
+    // dependent round trip per element made this kernel 60-80 us for a hundred tiles
     constexpr int U = 8;
-    for (int lj0 = threadIdx.x >> 7; lj0 < BN; lj0 += 2 * U) {
-        double sum[U], cin[U];
-        bool on[U];
+    const bool has_cin = (g.Cin != nullptr), has_dvec = (g.dvec != nullptr);
+    const int64_t gic = gi < g.M ? gi : g.M - 1;
+    for (int lj0 = threadIdx.x >> 7; lj0 < BN; lj0 += 2 * U) {  // lj0 + 2u <= 127
+        double sum[U], cin[U], dv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int lj = lj0 + 2 * u;
-            const int64_t gj = j0 + lj;
-            on[u] = lj < BN && gi < g.M && gj < g.N && !(g.lower_only && gi + g.diag_off < gj);
+            const int64_t gj = j0 + lj0 + 2 * u, gjc = gj < g.N ? gj : g.N - 1;
             sum[u] = 0.0;
-            cin[u] = (on[u] && g.Cin) ? g.Cin[gi + gj * g.ldcin] : 0.0;
+            cin[u] = has_cin ? g.Cin[gic + gjc * g.ldcin] : 0.0;
+            dv[u] = has_dvec ? g.dvec[gjc] : 0.0;
         }
         for (int sp = 0; sp < ksplit; ++sp) {  // split order: the same result on every run
             const double* w = work + ((int64_t)sp * ntiles + t) * (BM * BN) + li;
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (on[u]) sum[u] += w[(lj0 + 2 * u) * BM];
+            for (int u = 0; u < U; ++u) sum[u] += w[(lj0 + 2 * u) * BM];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!on[u]) continue;
             const int64_t gj = j0 + lj0 + 2 * u;
+            if (!(gi < g.M && gj < g.N) || (g.lower_only && gi + g.diag_off < gj)) continue;
             double val = g.alpha * sum[u];
-            if (g.Cin) val += g.beta * cin[u];
-            if (g.dvec && gi + g.diag_off == gj) val += g.dvec[gj];
+            if (has_cin) val += g.beta * cin[u];
+            if (has_dvec && gi + g.diag_off == gj) val += dv[u];
             g.C[gi + gj * g.ldc] = val;
         }
     }
