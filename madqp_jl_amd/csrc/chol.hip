@@ -958,10 +958,10 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
     const int64_t n = s->n;
     HIP_TRY(ctx, hipMemsetAsync(s->d_info, 0, sizeof(int32_t), ctx->stream));
     // mid-size matrices: right-looking, two launches per 128-column block (chol_mid_step_kernel)
-    // (measured on bench.py, m = 0.4 n: 1.55 against 1.78 ms per iteration at n = 1 000, 6.8 against 8.3 at 5 000,
-    // 13.9 against 16.6 at 8 000, 35.1 against 36.0 at 12 000; 69 against 67 at 16 000 -- every step rewrites the
-    // whole trailing matrix, which the left-looking schedule does not)
-    static const int64_t mid_max = getenv("MADQP_CHOL_MID_MAX") ? atoll(getenv("MADQP_CHOL_MID_MAX")) : 12288;
+    // (measured on bench.py, m = 0.4 n, ms per iteration against the left-looking schedule: 3.34 / 3.90 at n = 3 000,
+    // 6.37 / 7.51 at 5 000, 13.7 / 15.1 at 8 000, 22.7 / 23.2 at 10 000, 34.4 / 33.0 at 12 000 -- every step rewrites
+    // the whole trailing matrix, which the left-looking schedule does not)
+    static const int64_t mid_max = getenv("MADQP_CHOL_MID_MAX") ? atoll(getenv("MADQP_CHOL_MID_MAX")) : 10240;
     const int64_t npad_m = (n + NB - 1) / NB * NB;
     if (n <= mid_max && n > NB && s->npos == n && lda >= npad_m && lda % 2 == 0 && (((uintptr_t)A) & 15) == 0) {
         const int32_t nblk = (int32_t)(npad_m / NB);

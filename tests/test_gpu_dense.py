@@ -112,7 +112,7 @@ def _spd(n, rng, cond=1e3):
                          + [(n, True) for n in [129, 255, 300, 1024, 1100, 2300, 4100]])
 def test_cholesky_factor_and_solve(hip, n, padded):
     """padded: the leading dimension covers the order rounded up to 128, as the KKT objects allocate K -- the
-    layout that takes the right-looking mid-size schedule (chol.hip, chol_mid_step_kernel) up to n = 12 288."""
+    layout that takes the right-looking mid-size schedule (chol.hip, chol_mid_step_kernel) up to n = 10 240."""
     rng = np.random.default_rng(n)
     K = _spd(n, rng)
     K = 0.5 * (K + K.T)
