@@ -449,8 +449,9 @@ int32_t madqp_mpc_set_scalars(madqp_mpc* mpc, double mu, double del_w, double de
 /* src/solver.jl:259-283; status_host: 0 continue, 1 SOLVE_SUCCEEDED, 6 MAXIMUM_ITERATIONS_EXCEEDED */
 int32_t madqp_mpc_head(madqp_mpc* mpc, madqp_mpc_info* info_host, int32_t* status_host);
 /* src/solver.jl:288-343; returns MADQP_NUM_NAN for MadNLP.SolveException (src/linear_solver.jl:41-43).
- * Without Gondzio corrections, Mehrotra's adaptive step rule or refinement steps the reductions of an iteration are
- * queued in the context's result block and read back three times per iteration (csrc/mpc.hip, body_fused; the
+ * Unless Mehrotra's adaptive step rule or refinement steps are selected, the reductions of an iteration are queued in
+ * the context's result block and read back three times per iteration, plus twice per tried Gondzio correction
+ * (csrc/mpc.hip, body_fused; the
  * iterates are bitwise those of the sequential form, which MADQP_MPC_FUSED=0 selects when the object is created);
  * the residual norms of the next termination test come with the last of the three, so madqp_mpc_head behind a
  * body does not synchronise at all. */

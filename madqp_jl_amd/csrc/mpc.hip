@@ -6,9 +6,10 @@
 // where each host thread drives its own context).
 //
 // Blocking read-backs.  The sequential form (body_sequential: every reduction returns its scalar at once) makes about
-// ten per iteration.  The fused form (body_fused; AdaptiveStep / ConservativeStep without Gondzio corrections, which
-// is what the iteration count of a correction depends on) queues the reductions of a phase in the context's result
-// block and reads the block THREE times per iteration:
+// ten per iteration, thirteen to sixteen with Gondzio corrections.  The fused form (body_fused; AdaptiveStep /
+// ConservativeStep, no refinement steps) queues the reductions of a phase in the context's result block and reads the
+// block THREE times per iteration, plus twice per tried Gondzio correction (its complementarity estimate, then the
+// residual norms and step lengths that decide whether it is kept):
 //   (a) after the predictor: factorisation info, residual norms of solve_system!, the four step-length minima,
 //       the affine complementarity sums (whose kernel takes the step lengths from the block, not from the host)
 //       and the complementarity sums  -> sigma, mu on the host, in the arithmetic of the sequential form;
@@ -275,7 +276,7 @@ extern "C" int32_t madqp_mpc_create(madqp_kkt* kkt, const madqp_state* st, doubl
     s->reg_delta_p = opt->delta_p;
     s->reg_delta_d = opt->delta_d;
     const char* env = getenv("MADQP_MPC_FUSED");  // 0: the sequential form (A/B tests)
-    s->fused = !(env && env[0] == '0') && opt->max_ncorr == 0 && opt->step_rule != 2 && opt->refine_steps == 0;
+    s->fused = !(env && env[0] == '0') && opt->step_rule != 2 && opt->refine_steps == 0;
     *out = s;
     return MADQP_OK;
 }
@@ -419,18 +420,55 @@ int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
         sigma = std::min(std::max(std::pow(t, 3.0), 1e-6), 10.0);
     }
     s->mu = std::max(s->opt.mu_min, sigma * mu_curr);
-    // (b) corrector
+    // (b) corrector.  The step rule's minima and |dx| are queued behind every direction that may turn out to be the
+    // final one, so that the Gondzio loop below ends without a read-back of its own.
     TRY(madqp_set_correction_rhs(ctx, &s->st, s->mu));  // :307
     TRY(solve_system_queue(s, 0));
     const double tau = (s->opt.step_rule == 0) ? s->opt.step_param : std::max(1.0 - s->mu, s->opt.step_param);
+    const bool gz = s->opt.max_ncorr > 0;
+    const double gz_tau = 0.995, gz_delta = 0.1, gz_bmin = 0.1, gz_bmax = 10.0;  // src/solver.jl:200-251
     TRY(madqp_q_alpha_max(ctx, &s->st, tau, 3));
     TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, 11));  // print_iter, src/structure.jl:190
-    TRY(madqp_read_results(ctx, 14, r));
+    if (gz) TRY(madqp_q_alpha_max(ctx, &s->st, gz_tau, 14));
+    double rb[32];
+    TRY(madqp_read_results(ctx, gz ? 22 : 14, rb));
     s->n_readbacks += 1;
-    TRY(residual_verdict(s, r));
-    s->alpha_p = min_like_host(r[3], r[5]);
-    s->alpha_d = min_like_host(r[7], r[9]);
-    s->dnorm = r[11];
+    TRY(residual_verdict(s, rb));
+    s->alpha_p = min_like_host(rb[3], rb[5]);
+    s->alpha_d = min_like_host(rb[7], rb[9]);
+    s->dnorm = rb[11];
+    if (gz) {  // gondzio(), two read-backs per tried correction instead of three + the step rule's afterwards
+        const int64_t len = ntot(s->st);
+        double g_ap = min_like_host(rb[14], rb[16]), g_ad = min_like_host(rb[18], rb[20]);
+        for (int c = 0; c < s->opt.max_ncorr; ++c) {
+            const double ta_p = std::min(g_ap + gz_delta, 1.0), ta_d = std::min(g_ad + gz_delta, 1.0);
+            TRY(madqp_q_compl(ctx, &s->st, 1, ta_p, ta_d, nullptr, 0));
+            TRY(madqp_read_results(ctx, 2, rb));
+            s->n_readbacks += 1;
+            const double ga = nb ? (rb[0] + rb[1]) / (double)nb : 0.0;
+            const double mu_c = (ga / mu_curr) * (ga / mu_curr) * ga;
+            TRY(madqp_set_extra_correction(ctx, &s->st, ta_p, ta_d, gz_bmin, gz_bmax, mu_c));
+            TRY(madqp_set_correction_rhs(ctx, &s->st, mu_c));
+            TRY(madqp_copy(ctx, len, s->st.d, s->w2));
+            TRY(solve_system_queue(s, 0));
+            TRY(madqp_q_alpha_max(ctx, &s->st, gz_tau, 3));
+            TRY(madqp_q_alpha_max(ctx, &s->st, tau, 14));                          // in case this direction is kept
+            TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, 22));  // and is the last one
+            TRY(madqp_read_results(ctx, 25, rb));
+            s->n_readbacks += 1;
+            TRY(residual_verdict(s, rb));
+            const double ha_p = min_like_host(rb[3], rb[5]), ha_d = min_like_host(rb[7], rb[9]);
+            if (ha_p < 1.005 * g_ap || ha_d < 1.005 * g_ad) {
+                TRY(madqp_copy(ctx, len, s->w2, s->st.d));  // the direction before it, whose step is already known
+                break;
+            }
+            g_ap = ha_p;
+            g_ad = ha_d;
+            s->alpha_p = min_like_host(rb[14], rb[16]);
+            s->alpha_d = min_like_host(rb[18], rb[20]);
+            s->dnorm = rb[22];
+        }
+    }
     // (c) update, objective, and the residuals the next termination test needs
     TRY(madqp_update_iterates(ctx, &s->st, s->alpha_p, s->alpha_d));  // :332-335
     TRY(madqp_q_kkt_eval(s->kkt, &s->st, s->q, s->rhs, 0));           // :338-340

@@ -322,9 +322,10 @@ def test_native_driver_is_bitwise_the_python_driver(hip):
 
 def test_fused_iteration_is_bitwise_the_sequential_one_with_three_readbacks(hip):
     """csrc/mpc.hip, body_fused: the reductions of an iteration are queued in the result block and read back three
-    times (predictor, corrector, update + the next termination test) instead of once per reduction; kernels, host
-    arithmetic and stream order are those of the sequential form, so traces and iterates agree bit for bit -- also
-    when the first factorisation of an iteration fails and the x100 retry takes over."""
+    times (predictor, corrector, update + the next termination test; twice more per tried Gondzio correction)
+    instead of once per reduction; kernels, host arithmetic and stream order are those of the sequential form, so
+    traces and iterates agree bit for bit -- also when the first factorisation of an iteration fails and the x100
+    retry takes over."""
     import os
 
     def run(qp, fused, **kw):
@@ -348,15 +349,19 @@ def test_fused_iteration_is_bitwise_the_sequential_one_with_three_readbacks(hip)
              (Q.synthetic_qp(78, 120, 50, "lp"), dict(regularization=M.AdaptiveRegularization(1e-8, -1e-9, 1e-9)), True),
              (Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)),
               dict(regularization=M.FixedRegularization(1e-8, -1e-8), step_rule=M.ConservativeStep(0.99)), True),
-             (retry_qp, dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_iter=4), False))
+             (retry_qp, dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_iter=4), False),
+             (Q.synthetic_qp(77, 200, 80), dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=3), True),
+             (Q.synthetic_qp(81, 150, 60, "lp"), dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=2), True))
     for qp, kw, converges in cases:
         a, b = run(qp, False, **kw), run(qp, True, **kw)
         assert a["status"] == b["status"] and a["iter"] == b["iter"]
         assert (a["status"] == M.SOLVE_SUCCEEDED) == converges
         assert a["trace"] == b["trace"] and a["n_factorizations"] == b["n_factorizations"]
         assert np.array_equal(a["solution"], b["solution"]) and a["objective"] == b["objective"]
-        if converges:  # one read-back for the first termination test, three per iteration after that
+        if converges and not kw.get("max_ncorr"):  # one read-back for the first termination test, then three per iteration
             assert b["readbacks"] == 1 + 3 * b["iter"], (b["readbacks"], b["iter"])
+        elif converges:  # plus two per tried Gondzio correction, at most max_ncorr of them per iteration
+            assert 1 + 3 * b["iter"] < b["readbacks"] <= 1 + (3 + 2 * kw["max_ncorr"]) * b["iter"]
 
 
 def test_batch_of_independent_qps(hip):
