@@ -180,23 +180,29 @@ def test_sweeps_with_split_block_rows(hip, n, chunk):
     assert np.linalg.norm(xs[0] - xs[1]) / np.linalg.norm(xs[1]) < 1e-12
 
 
-def test_cholesky_not_positive_definite_reports_column(hip):
-    """LAPACK info convention: first failing leading minor, never aborts (SURVEY 8b errors)."""
+@pytest.mark.parametrize("padded", [False, True])
+def test_cholesky_not_positive_definite_reports_column(hip, padded):
+    """LAPACK info convention: first failing leading minor, never aborts (SURVEY 8b errors); both schedules of
+    madqp_chol_factor (padded leading dimension: the right-looking mid-size one)."""
     n = 300
     rng = np.random.default_rng(5)
     K = _spd(n, rng)
     K[200, 200] = -1.0
-    Kd = dev(np.tril(K).T.copy(), hip)
+    lda = 384 if padded else n
+    host = np.zeros((n, lda))
+    host[:, :n] = np.tril(K).T
+    Kd = dev(host, hip)
     h = hip.chol_create(n)
     try:
-        info = hip.chol_factor(h, Kd, n)
+        info = hip.chol_factor(h, Kd, lda)
         ref_info = sla.lapack.dpotrf(K, lower=1)[1]
         assert info == ref_info == 201
     finally:
         hip.chol_destroy(h)
 
 
-def test_cholesky_graded_ipm_like(hip):
+@pytest.mark.parametrize("padded", [False, True])
+def test_cholesky_graded_ipm_like(hip, padded):
     """Diagonal scaling over 16 orders of magnitude (late-IPM Sigma): backward error stays at eps."""
     n = 700
     rng = np.random.default_rng(11)
@@ -205,11 +211,14 @@ def test_cholesky_graded_ipm_like(hip):
     th = 10.0 ** rng.uniform(-6, 6, 300)
     K = (A.T * th) @ A + np.diag(sig)
     K = 0.5 * (K + K.T)
-    Kd = dev(np.tril(K).T.copy(), hip)
+    lda = 768 if padded else n
+    host = np.zeros((n, lda))
+    host[:, :n] = np.tril(K).T
+    Kd = dev(host, hip)
     h = hip.chol_create(n)
     try:
-        assert hip.chol_factor(h, Kd, n) == 0
-        L = np.tril(Kd.cpu().numpy().T)
+        assert hip.chol_factor(h, Kd, lda) == 0
+        L = np.tril(Kd.cpu().numpy()[:, :n].T)
         d = np.sqrt(np.diag(K))
         E = (L @ L.T - K) / np.outer(d, d)  # scaled backward error
         assert np.max(np.abs(E)) < 1e-13, np.max(np.abs(E))
