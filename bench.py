@@ -449,8 +449,61 @@ def bench_line(args, res, world):
     return out
 
 
+_REPORTER_SRC = r"""
+import sys
+held = None
+for line in sys.stdin:
+    line = line.rstrip("\n")
+    if line == "DONE":
+        sys.exit(0)
+    if line.startswith("HOLD "):
+        held = line[5:]
+if held is not None:  # the pipe closed without DONE: the bench process is gone (crash, or killed with its group)
+    sys.stdout.write(held + "\n")
+    sys.stdout.flush()
+"""
+
+
+class LastResortReporter:
+    """A child process of rank 0, started BEFORE anything initialises the GPU (a process that has touched the GPU
+    must not start programs on this pool).  It holds the JSON line of what is already measured; if the bench process
+    disappears before saying DONE -- a fault inside the never-before-run multi-GPU leg, or the launcher tearing the
+    group down because another rank died -- the child prints that line, so that the run still leaves its one line."""
+
+    def __init__(self, enabled):
+        import subprocess
+        self.p = None
+        if enabled:
+            try:
+                self.p = subprocess.Popen([sys.executable, "-c", _REPORTER_SRC], stdin=subprocess.PIPE, text=True)
+            except OSError:
+                self.p = None
+
+    def _send(self, text):
+        if self.p is not None and self.p.stdin is not None:
+            try:
+                self.p.stdin.write(text + "\n")
+                self.p.stdin.flush()
+            except (BrokenPipeError, OSError):
+                self.p = None
+
+    def hold(self, obj):
+        self._send("HOLD " + json.dumps(obj))
+
+    def done(self):
+        self._send("DONE")
+        if self.p is not None:
+            try:
+                self.p.stdin.close()
+                self.p.wait(timeout=5)
+            except Exception:
+                pass
+            self.p = None
+
+
 def main():
     args = parse()
+    reporter = LastResortReporter(int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0)
     import torch
     import torch.distributed as dist
 
@@ -515,6 +568,7 @@ def main():
                 state["printed"] = True
                 if rank == 0:
                     print(json.dumps(obj), flush=True)
+                reporter.done()
 
         def fallback(msg):
             if weak is None:
@@ -527,6 +581,10 @@ def main():
             emit(fallback(f"the shared-QP leg gave no result after {args.extra_timeout} s; exit code 3"))
             os._exit(3)
 
+        if rank == 0 and weak is not None:  # what a crash of the shared leg must not take with it
+            reporter.hold(fallback("the process ended inside the shared-QP leg (fault or killed with its group)"))
+        if os.environ.get("MADQP_BENCH_TEST_CRASH") and rank == 0:  # tests/test_bench.py: the reporter's reason to exist
+            os.kill(os.getpid(), 9)
         timer = threading.Timer(args.extra_timeout, bail)
         timer.daemon = True
         timer.start()
@@ -545,6 +603,7 @@ def main():
                                           "ms_per_step": weak["tmax"] / weak["steps"] * 1e3, "steps": weak["steps"]}
         emit(out)
 
+    reporter.done()
     be.close()
     if world > 1:
         dist.destroy_process_group()

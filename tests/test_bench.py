@@ -48,3 +48,30 @@ def test_total_counter_without_reinit_equals_kkt_counter():
     loop.step()
     assert loop.reinits == 0 and loop.factorizations() == 2
     assert s.n_factorizations_total == s.kkt.n_factorizations == 3  # start point + 2 iterations
+
+
+def test_last_resort_reporter_prints_the_held_line_only_when_the_bench_process_dies():
+    """bench.py, N > 1: the independent-QPs result is handed to a child process (started before anything touches the
+    GPU) before the never-before-run multi-GPU leg starts; if the bench process disappears without saying DONE the
+    child prints that line, otherwise nothing -- the run leaves exactly one JSON line either way."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent('''
+        import json, os, sys
+        sys.path.insert(0, %r)
+        import bench
+        r = bench.LastResortReporter(True)
+        r.hold({"metric": "held", "value": 1})
+        if sys.argv[1] == "crash":
+            os.kill(os.getpid(), 9)
+        print(json.dumps({"metric": "real"}), flush=True)
+        r.done()
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode, expect in (("crash", "held"), ("ok", "real")):
+        out = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=60)
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1 and json.loads(lines[0])["metric"] == expect, (mode, out.stdout, out.stderr)
