@@ -1,4 +1,4 @@
-// Blocked left-looking fp64 Cholesky (lower, column-major, in place) and the triangular solves.
+// Blocked fp64 Cholesky (lower, column-major, in place) and the triangular solves.
 //
 // Replaces the AbstractLinearSolver used behind NormalKKTSystem (MadNLP.LapackCPUSolver -> LAPACK
 // dpotrf/dpotrs; reference call sites src/KKT/normalkkt.jl:99-101,196, src/linear_solver.jl:10-11).
@@ -11,10 +11,12 @@
 //     down to 128-column blocks jb:
 //       L_jj = chol(C_jj),  W_jj = L_jj^-1                   one workgroup, block resident in LDS
 //       L[jb+128:n, jb] = C[jb+128:n, jb] * W_jj'            gemm core, K = N = 128        (MFMA)
+// Matrices up to n = 10 240 take a right-looking schedule instead (chol_mid_step_kernel below): two launches per
+// 128-column block, the diagonal block factored inside the launch that updates the trailing tiles.
 // The inverse diagonal blocks W are kept (two images, 2 x n x 128 doubles) and turn the diagonal
 // solves of the two triangular sweeps into 128 x 128 mat-vecs; each sweep is ONE launch of
 // ticket-ordered workgroups handing the solved blocks on through a sentinel-tagged vector, HBM bound
-// (4 n^2 bytes).  Also here: the same factorisation for a batch of small matrices
+// (4 n^2 bytes); block rows longer than 64 tiles are streamed by several workgroups (SweepPlan).  Also here: the same factorisation for a batch of small matrices
 // (madqp_chol_factor_batched) and its pieces for the multi-GPU panel loop (madqp_chol_factor_panel, ...).
 #include <algorithm>
 #include <cstdlib>
