@@ -168,6 +168,37 @@ class DistCholesky2D:
 
 # =====================================================================================================
 # One QP shared by all ranks: what a rank holds of it, and the KKT system above madqp_dkkt_*
+def reduce_where(backend_name: str, tensor_is_cuda: bool) -> str:
+    """Where a tensor must live for a collective on the default process group: RCCL ("nccl") has no backend for CPU
+    tensors and gloo none (worth relying on) for device tensors, so the tensor goes where the group's backend is --
+    "as_is" when it already is there, else "to_cpu" (rehearsals: gloo with the data on a GPU).  A device tensor on
+    an nccl group is reduced in place on the device: `bench.py --gpus N` initialises nccl only."""
+    name = backend_name.lower()
+    has_cuda = "nccl" in name
+    has_cpu = "gloo" in name or "mpi" in name
+    if tensor_is_cuda:
+        if has_cuda:
+            return "as_is"
+        if has_cpu:
+            return "to_cpu"
+        raise RuntimeError(f"process group backend {backend_name!r} can reduce neither device nor host tensors")
+    if has_cpu:
+        return "as_is"
+    raise RuntimeError(f"process group backend {backend_name!r} has no CPU backend: keep the tensor on the device")
+
+
+def all_reduce_replicated(t, op):
+    """all_reduce of a replicated vector over the default process group, on the device the group's backend serves."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return t
+    if reduce_where(str(dist.get_backend()), t.is_cuda) == "as_is":
+        dist.all_reduce(t, op=op)
+        return t
+    c = t.cpu()
+    dist.all_reduce(c, op=op)
+    return c.to(t.device)
+
+
 def _cyclic_index(count_local, nb, R, r, device):
     """Global index of every local row / column of a direction with modulus R and residue r."""
     c = torch.arange(count_local, device=device)
@@ -249,11 +280,7 @@ class DistributedQP:
     def row_absmax(self):
         """max_j |A[k, j]| per row, over all ranks."""
         r = self.A_I[: self.ncon].abs().amax(dim=1) if self.ncon and self.grid.mloc else torch.zeros(self.ncon, dtype=torch.float64, device=self.q.device)
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            c = r.cpu()
-            dist.all_reduce(c, op=dist.ReduceOp.MAX)
-            r = c.to(r.device)
-        return r
+        return all_reduce_replicated(r, dist.ReduceOp.MAX)
 
     def hess_times(self, x):
         """H x from the local tiles (each lower tile once, its mirror image too), summed over the ranks."""
@@ -267,11 +294,7 @@ class DistributedQP:
             strict = (gi[None, :] // g.nb) > (gj[:, None] // g.nb)
             y.index_add_(0, gi, (Hl * lower).t() @ x[gj])
             y.index_add_(0, gj, (Hl * strict) @ x[gi])
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            c = y.cpu()
-            dist.all_reduce(c)
-            y = c.to(y.device)
-        return y
+        return all_reduce_replicated(y, dist.ReduceOp.SUM)
 
 
 class HIPDistributedCondensedKKTSystem2D:

@@ -28,6 +28,21 @@ def test_two_ranks_gloo(tmp_path):
     assert abs(recs[0]["value"] - 2 * 3 / recs[0]["tmax"]) < 1e-9
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "only rank 0 prints the JSON line"
+    # the set-up collectives of a shared QP (dist2d.DistributedQP) over the same process group
+    assert all(r["rowmax_err"] == 0.0 and r["hx_err"] < 1e-13 for r in recs)
+
+
+def test_setup_collectives_follow_the_group_backend():
+    """`bench.py --gpus N` initialises nccl only, and RCCL has no backend for CPU tensors -- the
+    replicated set-up reductions must stay on the device there and go through the host only under gloo."""
+    sys.path.insert(0, ROOT)
+    from madqp_jl_amd.dist2d import reduce_where
+
+    assert reduce_where("nccl", True) == "as_is"
+    assert reduce_where("cpu:gloo,cuda:nccl", True) == "as_is" and reduce_where("cpu:gloo,cuda:nccl", False) == "as_is"
+    assert reduce_where("gloo", True) == "to_cpu" and reduce_where("gloo", False) == "as_is"
+    with pytest.raises(RuntimeError):
+        reduce_where("nccl", False)  # what round 2 did: a CPU tensor on an nccl-only group
 
 
 @pytest.mark.parametrize("world,n,nb,port", [(2, 700, 128, 29519), (3, 1000, 256, 29521), (2, 400, 512, 29523)])
