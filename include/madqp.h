@@ -360,20 +360,26 @@ int32_t madqp_chol_factor_end(madqp_chol* s, int32_t* info_host);
  *   factor   right-looking over tile columns with look-ahead 1: diagonal tile -> broadcast down its process column ->
  *            panel solves -> the panel is broadcast along process rows and, transposed, down process columns -> one
  *            MFMA GEMM per rank and step; info as LAPACK dpotrf, identical on all ranks;
- *   solve    rhs: n doubles, replicated on every rank, overwritten with the solution (forward and backward sweeps
- *            over the tiles: one reduction to the diagonal owner and one broadcast per tile).
+ *   solve    rhs: n doubles, replicated on every rank, overwritten with the solution.  Forward and backward sweeps
+ *            over GROUPS of G tiles (G nb = 4096 rows by default): during the factorisation the G x G tile triangle on
+ *            the diagonal of each group is collected on one rank (group g -> rank g mod world; point-to-point, <= G
+ *            tiles per step, behind the operand broadcasts), so a sweep costs one reduction of the group's partial sums
+ *            to that rank, one local triangular solve of order G nb and one broadcast per GROUP, not per tile.
  * Collectives: RCCL over xGMI -- rank 0 draws an id with madqp_dist_unique_id and the caller ships those 128 bytes to
  * every rank (any channel), create builds the world / row / column communicators; the calls run on internal streams
  * of the context, ordered after what the context's stream held at the call and finished (joined) before it goes on.
  * For rehearsals with several ranks on one GPU (RCCL refuses that) the caller passes host-staged collectives instead
  * (madqp_comm_ops; tests use torch.distributed gloo): group 0 = world, 1 = my process row, 2 = my process column;
- * root = rank inside the group (q in a row group, p in a column group). */
+ * root = rank inside the group (q in a row group, p in a column group); send / recv: blocking point-to-point between
+ * world ranks (never to oneself). */
 typedef struct madqp_dist madqp_dist;
 typedef struct madqp_comm_ops {
     void* user;
     int32_t (*bcast)(void* user, void* host_buf, int64_t bytes, int32_t root, int32_t group);
     int32_t (*reduce_sum)(void* user, double* host_buf, int64_t count, int32_t root, int32_t group);
     int32_t (*allreduce_sum)(void* user, double* host_buf, int64_t count, int32_t group);
+    int32_t (*send)(void* user, const void* host_buf, int64_t bytes, int32_t dst_world_rank);
+    int32_t (*recv)(void* user, void* host_buf, int64_t bytes, int32_t src_world_rank);
 } madqp_comm_ops;
 int32_t madqp_dist_unique_id(madqp_ctx* ctx, void* id128);
 /* nccl_id128: the 128 bytes of madqp_dist_unique_id (ignored when world == 1 or ops != NULL); ops: NULL = RCCL */

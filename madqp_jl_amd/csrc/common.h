@@ -24,6 +24,11 @@ struct madqp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int64_t gemm_slots = 512;  // resident GEMM workgroups: 2 per CU
+    // > 0: GEMM launches with more tiles than (gemm_slots - gemm_cap_slots) run as ONE persistent launch of that many
+    // workgroups drawing tiles from per-XCD ticket counters, leaving gemm_cap_slots workgroup slots of the chip free
+    // for kernels on other streams (dist.hip: the collectives beside a trailing update).  0: one workgroup per tile.
+    int64_t gemm_cap_slots = 0;
+    unsigned long long* d_tickets = nullptr;  // 8 counters, zeroed on the stream before every capped launch
     char err[512] = {0};
     // scalar results: device block + pinned host mirror
     double* d_res = nullptr;

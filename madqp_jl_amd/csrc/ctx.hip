@@ -47,6 +47,7 @@ extern "C" int32_t madqp_ctx_destroy(madqp_ctx* ctx) {
     if (ctx->d_part) (void)hipFree(ctx->d_part);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_scaled) (void)hipFree(ctx->d_scaled);
+    if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
     delete ctx;
     return MADQP_OK;
 }

@@ -24,6 +24,10 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -46,16 +50,24 @@ Rccl& rccl() {
     RSYM(Broadcast, "ncclBroadcast");
     RSYM(Reduce, "ncclReduce");
     RSYM(AllReduce, "ncclAllReduce");
+    RSYM(Send, "ncclSend");
+    RSYM(Recv, "ncclRecv");
+    RSYM(GroupStart, "ncclGroupStart");
+    RSYM(GroupEnd, "ncclGroupEnd");
     RSYM(GetErrorString, "ncclGetErrorString");
 #undef RSYM
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommSplit && r.CommDestroy && r.Broadcast && r.Reduce && r.AllReduce;
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommSplit && r.CommDestroy && r.Broadcast && r.Reduce && r.AllReduce &&
+           r.Send && r.Recv && r.GroupStart && r.GroupEnd;
     return r;
 }
 
+constexpr int DIST_NEV = 8;
 struct Dev {
     madqp_ctx* ctx;
-    hipStream_t main, sP, sU;  // caller's stream, panel stream, update stream
-    hipEvent_t ev[3];
+    hipStream_t main, sP, sU;  // caller's stream, communication stream, kernel stream
+    hipEvent_t ev[DIST_NEV], ev_main;
+    int ev_next;
+    int free_slots;  // workgroup slots the bulk updates leave to the collectives (0 = ordinary launches)
     madqp_chol* chol_nb;    // order nb: diagonal tiles
     madqp_chol* chol_last;  // order of the (partial) last tile, or nullptr
     int64_t nb, wlast;
@@ -128,6 +140,21 @@ __global__ void dist_info_global_kernel(double* hdr, double col0, double* info) 
 }
 __global__ __launch_bounds__(256) void dist_vsub_kernel(double* a, const double* b, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a[i] -= b[i];
+}
+// out[i] = loc[((I0 + i/nb) div R) nb + i mod nb] when tile I0 + i/nb belongs to residue r (mod R), else 0
+__global__ __launch_bounds__(256) void dist_group_pack_kernel(double* __restrict__ out, const double* __restrict__ loc,
+                                                              int64_t I0, int64_t wg, int64_t nb, int64_t R, int64_t r) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < wg; i += (int64_t)gridDim.x * 256) {
+        const int64_t I = I0 + i / nb;
+        out[i] = (I % R == r) ? loc[(I / R) * nb + i % nb] : 0.0;
+    }
+}
+int32_t dop_group_pack(Dev* dev, double* out, const double* loc, int64_t I0, int64_t wg, int64_t nb, int64_t R, int64_t r) {
+    if (wg <= 0) return 0;
+    hipLaunchKernelGGL(dist_group_pack_kernel, dim3((unsigned)std::min<int64_t>((wg + 255) / 256, 1024)), dim3(256), 0,
+                       dev->ctx->stream, out, loc, I0, wg, nb, R, r);
+    LAUNCH_CHECK(dev->ctx);
+    return 0;
 }
 int32_t dop_info_store(Dev* dev, const double* info, double* hdr) {
     hipLaunchKernelGGL(dist_info_store_kernel, dim3(1), dim3(1), 0, dev->ctx->stream, info, hdr);
@@ -241,38 +268,80 @@ int32_t dop_tile_solve(Dev* dev, int32_t trans, const double* L, int64_t ld, con
     return madqp_trsv_tile(dev->ctx, trans, L, ld, W, v, w, scratch, dev->ctl);
 }
 
-// ---- streams (dist_core.inc): kernels on sU, collectives on sP.  0 begin, 1 U -> P, 2 P -> U, 3 back to U without waiting, 4 join
-int32_t dop_phase(Dev* dev, int code) {
-    madqp_ctx* ctx = dev->ctx;
+// ---- streams (dist_core.inc): kernels on sU, collectives on sP
+int32_t dop_stream(Dev* dev, int which) {
+    if (dev->two_streams) dev->ctx->stream = which ? dev->sP : dev->sU;
+    return 0;
+}
+// everything queued on `from` so far happens before whatever is queued on `to` from now on
+int32_t dop_link(Dev* dev, int from, int to) {
     if (!dev->two_streams) return 0;
-    switch (code) {
-        case 0:
-            HIP_TRY(ctx, hipEventRecord(dev->ev[0], dev->main));
-            HIP_TRY(ctx, hipStreamWaitEvent(dev->sP, dev->ev[0], 0));
-            HIP_TRY(ctx, hipStreamWaitEvent(dev->sU, dev->ev[0], 0));
-            ctx->stream = dev->sU;
-            break;
-        case 1:
-            HIP_TRY(ctx, hipEventRecord(dev->ev[1], dev->sU));
-            HIP_TRY(ctx, hipStreamWaitEvent(dev->sP, dev->ev[1], 0));
-            ctx->stream = dev->sP;
-            break;
-        case 2:
-            HIP_TRY(ctx, hipEventRecord(dev->ev[2], dev->sP));
-            HIP_TRY(ctx, hipStreamWaitEvent(dev->sU, dev->ev[2], 0));
-            ctx->stream = dev->sU;
-            break;
-        case 3:
-            ctx->stream = dev->sU;
-            break;
-        default:
-            HIP_TRY(ctx, hipEventRecord(dev->ev[1], dev->sP));
-            HIP_TRY(ctx, hipEventRecord(dev->ev[2], dev->sU));
-            HIP_TRY(ctx, hipStreamWaitEvent(dev->main, dev->ev[1], 0));
-            HIP_TRY(ctx, hipStreamWaitEvent(dev->main, dev->ev[2], 0));
-            ctx->stream = dev->main;
-            break;
+    madqp_ctx* ctx = dev->ctx;
+    hipEvent_t e = dev->ev[dev->ev_next];
+    dev->ev_next = (dev->ev_next + 1) % DIST_NEV;  // a wait captures the record before it: slots may be re-recorded
+    HIP_TRY(ctx, hipEventRecord(e, from ? dev->sP : dev->sU));
+    HIP_TRY(ctx, hipStreamWaitEvent(to ? dev->sP : dev->sU, e, 0));
+    return 0;
+}
+int32_t dop_fork(Dev* dev) {
+    if (!dev->two_streams) return 0;
+    madqp_ctx* ctx = dev->ctx;
+    HIP_TRY(ctx, hipEventRecord(dev->ev_main, dev->main));
+    HIP_TRY(ctx, hipStreamWaitEvent(dev->sP, dev->ev_main, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(dev->sU, dev->ev_main, 0));
+    ctx->stream = dev->sU;
+    return 0;
+}
+// the caller's stream waits for both internal streams; the context is back on the caller's stream whatever happens
+int32_t dop_join(Dev* dev) {
+    if (!dev->two_streams) return 0;
+    madqp_ctx* ctx = dev->ctx;
+    ctx->stream = dev->main;
+    hipError_t e1 = hipEventRecord(dev->ev[0], dev->sP);
+    hipError_t e2 = hipEventRecord(dev->ev[1], dev->sU);
+    if (e1 == hipSuccess) e1 = hipStreamWaitEvent(dev->main, dev->ev[0], 0);
+    if (e2 == hipSuccess) e2 = hipStreamWaitEvent(dev->main, dev->ev[1], 0);
+    if (e1 != hipSuccess || e2 != hipSuccess) {  // last resort: drain them on the host
+        (void)hipStreamSynchronize(dev->sP);
+        (void)hipStreamSynchronize(dev->sU);
     }
+    HIP_TRY(ctx, e1);
+    HIP_TRY(ctx, e2);
+    return 0;
+}
+inline void dop_mark(Dev*, int, int64_t) {}  // schedule recorder of the CPU build (tests/csrc/dist_cpu.cpp)
+// the bulk of a trailing update runs as a persistent launch of (resident slots - free_slots) workgroups, so that the
+// kernels of the collectives travelling beside it (RCCL's, the packing kernels) find room on the chip at once
+int32_t dop_bulk(Dev* dev, int on) {
+    dev->ctx->gemm_cap_slots = on ? dev->free_slots : 0;
+    return 0;
+}
+
+// dst tile t (at dst + t*dstep, leading dimension ldd) <- src tile t (src + t*sstep, lds): rows_t x w with
+// rows_t = clamp(limit - t*lstep, 0, nb); rows rows_t .. nb-1 of the destination are zeroed when zero_pad
+__global__ __launch_bounds__(256) void dist_gather_tiles_kernel(double* __restrict__ dst, int64_t ldd, int64_t dstep,
+                                                                const double* __restrict__ src, int64_t lds,
+                                                                int64_t sstep, int64_t nb, int64_t w, int64_t limit,
+                                                                int64_t lstep, int zero_pad) {
+    const int64_t t = blockIdx.z;
+    int64_t rows = limit - t * lstep;
+    rows = rows < 0 ? 0 : (rows > nb ? nb : rows);
+    const int64_t rend = zero_pad ? nb : rows;
+    const double* S = src + t * sstep;
+    double* D = dst + t * dstep;
+    for (int64_t c = blockIdx.y; c < w; c += gridDim.y)
+        for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rend; r += (int64_t)gridDim.x * 256)
+            D[r + c * ldd] = (r < rows) ? S[r + c * lds] : 0.0;
+}
+int32_t dop_gather_tiles(Dev* dev, double* dst, int64_t ldd, int64_t dstep, const double* src, int64_t lds, int64_t sstep,
+                         int64_t count, int64_t nb, int64_t w, int64_t limit, int64_t lstep, int zero_pad) {
+    if (count <= 0 || w <= 0) return 0;
+    madqp_ctx* ctx = dev->ctx;
+    ARG_TRY(ctx, count <= 65535);
+    const dim3 grid((unsigned)((nb + 255) / 256), (unsigned)std::min<int64_t>(w, 256), (unsigned)count);
+    hipLaunchKernelGGL(dist_gather_tiles_kernel, grid, dim3(256), 0, ctx->stream, dst, ldd, dstep, src, lds, sstep, nb, w,
+                       limit, lstep, zero_pad);
+    LAUNCH_CHECK(ctx);
     return 0;
 }
 
@@ -289,6 +358,18 @@ int32_t dop_nccl_allreduce(Dev* dev, void* comm, double* buf, int64_t count) {
     NCCL_TRY(dev, rccl().AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)comm, dev->ctx->stream));
     return 0;
 }
+int32_t dop_nccl_send(Dev* dev, void* comm, const double* buf, int64_t count, int dst) {
+    NCCL_TRY(dev, rccl().Send(buf, (size_t)count, ncclDouble, dst, (ncclComm_t)comm, dev->ctx->stream));
+    return 0;
+}
+int32_t dop_nccl_recv(Dev* dev, void* comm, double* buf, int64_t count, int src) {
+    NCCL_TRY(dev, rccl().Recv(buf, (size_t)count, ncclDouble, src, (ncclComm_t)comm, dev->ctx->stream));
+    return 0;
+}
+int32_t dop_nccl_group(Dev* dev, int begin) {
+    NCCL_TRY(dev, begin ? rccl().GroupStart() : rccl().GroupEnd());
+    return 0;
+}
 }  // namespace
 
 #include "dist_core.inc"
@@ -301,6 +382,7 @@ void dev_destroy(Dev* dev) {
     if (dev->ctl) (void)hipFree(dev->ctl);
     for (auto& e : dev->ev)
         if (e) (void)hipEventDestroy(e);
+    if (dev->ev_main) (void)hipEventDestroy(dev->ev_main);
     if (dev->sP) (void)hipStreamDestroy(dev->sP);
     if (dev->sU) (void)hipStreamDestroy(dev->sU);
     delete dev;
@@ -336,7 +418,7 @@ extern "C" int32_t madqp_dist_create(madqp_ctx* ctx, int32_t rank, int32_t world
     *out = nullptr;
     ARG_TRY(ctx, P >= 1 && Q >= 1 && P * Q == world && rank >= 0 && rank < world && n >= 0 && nb >= 128 && nb % 128 == 0);
     ARG_TRY(ctx, world == 1 || ops || nccl_id128);
-    ARG_TRY(ctx, !ops || (ops->bcast && ops->reduce_sum && ops->allreduce_sum));
+    ARG_TRY(ctx, !ops || (ops->bcast && ops->reduce_sum && ops->allreduce_sum && ops->send && ops->recv));
     Dev* dev = new (std::nothrow) Dev();
     if (!dev) return madqp_fail(ctx, MADQP_ERR_ALLOC, "host allocation failed");
     memset(dev, 0, sizeof(*dev));
@@ -352,8 +434,12 @@ extern "C" int32_t madqp_dist_create(madqp_ctx* ctx, int32_t rank, int32_t world
     if (e == hipSuccess && dev->two_streams) {
         e = hipStreamCreateWithFlags(&dev->sP, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&dev->sU, hipStreamNonBlocking);
-        for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&dev->ev[i], hipEventDisableTiming);
+        for (int i = 0; i < DIST_NEV && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&dev->ev[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&dev->ev_main, hipEventDisableTiming);
     }
+    // MADQP_DIST_FREE_SLOTS: of the 2 x #CU resident GEMM workgroups, how many the bulk updates leave free while
+    // collectives travel beside them (default: 16 with several ranks over RCCL, 0 otherwise; cost on one GPU: DESIGN.md 7)
+    dev->free_slots = getenv("MADQP_DIST_FREE_SLOTS") ? atoi(getenv("MADQP_DIST_FREE_SLOTS")) : ((world > 1 && !ops) ? 16 : 0);
     int32_t r = (e == hipSuccess) ? MADQP_OK : madqp_fail(ctx, MADQP_ERR_HIP, "madqp_dist_create: %s", hipGetErrorString(e));
     if (!r && n > 0) r = madqp_chol_create(ctx, std::min(nb, n), &dev->chol_nb);
     if (!r && dev->wlast && dev->wlast != std::min(nb, n)) r = madqp_chol_create(ctx, dev->wlast, &dev->chol_last);
@@ -427,14 +513,18 @@ extern "C" int32_t madqp_dist_matrix(madqp_dist* d, double** K, int64_t* ld) {
 
 extern "C" int32_t madqp_dist_factor(madqp_dist* d, int32_t* info_host) {
     if (!d || !info_host) return MADQP_ERR_ARG;
-    int32_t r = distcore::factor(d, info_host);
-    if (r && d->dev->two_streams) d->dev->ctx->stream = d->dev->main;  // never leave the context on an internal stream
+    // on any error distcore::factor has already joined both internal streams into the caller's (dop_join)
+    const int32_t r = distcore::factor(d, info_host);
+    d->dev->ctx->gemm_cap_slots = 0;
+    if (d->dev->two_streams) d->dev->ctx->stream = d->dev->main;
     return r;
 }
 
 extern "C" int32_t madqp_dist_solve(madqp_dist* d, double* rhs) {
     if (!d) return MADQP_ERR_ARG;
     ARG_TRY(d->dev->ctx, rhs || d->n == 0);
+    if (!d->factored)  // a factorisation that ended in an error leaves no factor (info > 0 is not an error: unit pivots)
+        return madqp_fail(d->dev->ctx, MADQP_ERR_STATE, "madqp_dist_solve: no completed factorisation");
     return distcore::solve(d, rhs);
 }
 

@@ -61,9 +61,8 @@ struct KArgs {
 #endif
 };
 
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
-    __shared__ __attribute__((aligned(16))) double lds[4 * TILE_DOUBLES];
-    GemmArgs g = ka.g;
+// wave-uniform operand offsets of a split-K chunk / of problem blockIdx.y of a batch; false: nothing to do
+__device__ __forceinline__ bool gemm_select(const KArgs& ka, GemmArgs& g) {
     if (ka.ksplit > 1) {
         const int64_t k0 = (int64_t)blockIdx.y * ka.kchunk;
         g.X += k0 * g.ldx;
@@ -71,21 +70,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
         g.K = (g.K - k0 < ka.kchunk) ? (g.K - k0) : ka.kchunk;
     } else if (ka.batch.B > 1) {  // wave-uniform pointer offsets of problem blockIdx.y
         const int64_t b = blockIdx.y;
-        if (ka.batch.skip && ka.batch.skip[b] != 0) return;
+        if (ka.batch.skip && ka.batch.skip[b] != 0) return false;
         g.X += b * ka.batch.sX;
         g.Y += b * ka.batch.sY;
         g.C += b * ka.batch.sC;
         if (g.Cin) g.Cin += b * ka.batch.sCin;
         if (g.dvec) g.dvec += b * ka.batch.sD;
     }
-    // Tile selection: the table is cut into 8 contiguous chunks, one per XCD (workgroup ids equal
-    // mod 8 share an XCD under the observed round-robin dispatch; claiming tiles by the real
-    // HW_REG_XCC_ID gave the same traffic and time, so the static map is kept).  Speed only: any
-    // placement computes the same result.
-    const int bid = blockIdx.x, T = ka.ntiles;
-    const int xcd = bid & 7, q = T >> 3, r = T & 7;
+    return true;
+}
+
+// one 128 x 128 output tile (entry t of the tile table) by the calling workgroup
+__device__ __forceinline__ void gemm_tile(const KArgs& ka, const GemmArgs& g, int t, int bid, double* lds) {
     const int tid = threadIdx.x;
-    const int t = ka.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
     const int32_t packed = ka.table[t];
     const int64_t i0 = (int64_t)(packed >> 16) * BM;
     const int64_t j0 = (int64_t)(packed & 0xFFFF) * BN;
@@ -169,6 +166,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
             const int64_t gj = j0 + tid, gi = gj - g.diag_off;
             if (gj < g.N && gi >= i0 && gi < i0 + BM && gi < g.M) g.C[gi + gj * g.ldc] += g.dvec[gj];
         }
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
+    __shared__ __attribute__((aligned(16))) double lds[4 * TILE_DOUBLES];
+    GemmArgs g = ka.g;
+    if (!gemm_select(ka, g)) return;
+    // Tile selection: the table is cut into 8 contiguous chunks, one per XCD (workgroup ids equal
+    // mod 8 share an XCD under the observed round-robin dispatch; claiming tiles by the real
+    // HW_REG_XCC_ID gave the same traffic and time, so the static map is kept).  Speed only: any
+    // placement computes the same result.
+    const int bid = blockIdx.x, T = ka.ntiles;
+    const int xcd = bid & 7, q = T >> 3, r = T & 7;
+    const int t = ka.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
+    gemm_tile(ka, g, t, bid, lds);
+}
+
+// The same tiles by a FIXED number of workgroups (gridDim.x, a multiple of 8, fewer than the chip holds): each draws
+// tiles of its XCD's chunk of the table from that XCD's ticket counter until the chunk is used up.  Which workgroup
+// computes a tile does not enter the result.  The eight counters are zeroed on the stream before the launch.
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_persistent_kernel(KArgs ka, unsigned long long* tickets) {
+    __shared__ __attribute__((aligned(16))) double lds[4 * TILE_DOUBLES];
+    __shared__ int next_tile;
+    const GemmArgs g = ka.g;
+    const int bid = blockIdx.x, T = ka.ntiles;
+    const int xcd = bid & 7, q = T >> 3, r = T & 7;
+    const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int chunk = q + (xcd < r ? 1 : 0);
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const unsigned long long tix = atomicAdd(tickets + xcd, 1ull);
+            next_tile = tix < (unsigned long long)chunk ? chunk0 + (int)tix : -1;
+        }
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(next_tile);
+        if (t < 0) break;
+        gemm_tile(ka, g, t, bid, lds);
+        __syncthreads();  // the LDS image and next_tile are reused
     }
 }
 
@@ -379,6 +414,17 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
     const int32_t* table0 = ka.table;
     const int32_t total = ka.ntiles;
     ProfScope ps(ctx, prof_cls);
+    // capped launch (ctx->gemm_cap_slots, set by dist.hip around a bulk trailing update): a persistent grid that leaves
+    // workgroup slots free for the kernels of other streams
+    const int64_t capped = ctx->gemm_cap_slots > 0 ? std::max<int64_t>(8, (ctx->gemm_slots - ctx->gemm_cap_slots) / 8 * 8) : 0;
+    if (capped && ka.ksplit == 1 && !batch && total > capped) {
+        if (!ctx->d_tickets) HIP_TRY(ctx, hipMalloc(&ctx->d_tickets, 8 * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_tickets, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(gemm_tn_f64_persistent_kernel, dim3((unsigned)capped), dim3(NTHREADS), 0, ctx->stream, ka,
+                           ctx->d_tickets);
+        LAUNCH_CHECK(ctx);
+        return MADQP_OK;
+    }
     for (int64_t off = 0; off < total; off += seg) {
         int64_t cnt = std::min<int64_t>(seg, total - off);
         if (total - off - cnt < seg / 4) cnt = total - off;  // no tiny last segment

@@ -22,12 +22,14 @@ GRP_WORLD, GRP_ROW, GRP_COL = 0, 1, 2
 _BCAST = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
 _REDUCE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
 _ALLREDUCE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+_P2P = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
 
 
 class CCommOps(C.Structure):
     """``madqp_comm_ops`` of include/madqp.h."""
 
-    _fields_ = [("user", C.c_void_p), ("bcast", _BCAST), ("reduce_sum", _REDUCE), ("allreduce_sum", _ALLREDUCE)]
+    _fields_ = [("user", C.c_void_p), ("bcast", _BCAST), ("reduce_sum", _REDUCE), ("allreduce_sum", _ALLREDUCE),
+                ("send", _P2P), ("recv", _P2P)]
 
 
 def default_grid(world: int):
@@ -57,9 +59,10 @@ class HostStagedComm:
         cols = [dist.new_group([pp * Q + qq for pp in range(P)], backend="gloo") for qq in range(Q)]
         world = dist.new_group(list(range(self.world)), backend="gloo")
         self.groups = {GRP_WORLD: world, GRP_ROW: rows[self.p], GRP_COL: cols[self.q]}
-        self.calls = {"bcast": 0, "reduce": 0, "allreduce": 0}
+        self.calls = {"bcast": 0, "reduce": 0, "allreduce": 0, "send": 0, "recv": 0}
         self.error = None
-        self._cb = (_BCAST(self._bcast), _REDUCE(self._reduce), _ALLREDUCE(self._allreduce))  # keep alive
+        self._cb = (_BCAST(self._bcast), _REDUCE(self._reduce), _ALLREDUCE(self._allreduce), _P2P(self._send),
+                    _P2P(self._recv))  # keep alive
         self.ops = CCommOps(None, *self._cb)
 
     def _global(self, root, g):
@@ -93,6 +96,25 @@ class HostStagedComm:
         try:
             self.calls["allreduce"] += 1
             dist.all_reduce(self._tensor(buf, count, torch.float64), op=dist.ReduceOp.SUM, group=self.groups[g])
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+
+    def _send(self, user, buf, nbytes, dst):
+        try:
+            self.calls["send"] += 1
+            dist.send(self._tensor(buf, nbytes, torch.uint8), dst=dst, group=self.groups[GRP_WORLD])
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+    def _recv(self, user, buf, nbytes, src):
+        try:
+            self.calls["recv"] += 1
+            dist.recv(self._tensor(buf, nbytes, torch.uint8), src=src, group=self.groups[GRP_WORLD])
             return 0
         except Exception as e:
             self.error = e

@@ -12,8 +12,12 @@
 
 #include "../../include/madqp.h"
 
+#include <vector>
+
+// the schedule recorder: every dop_mark() of dist_core.inc and which "stream" it was issued on, in program order
 struct Dev {
-    int dummy;
+    int stream = 0;                 // 0 = kernel stream U, 1 = communication stream P (dop_stream)
+    std::vector<int64_t> trace;     // triples (mark, k, stream) and (-1, from, to) for dop_link
 };
 
 static void* dop_alloc(Dev*, size_t bytes) { return calloc(1, bytes); }
@@ -144,10 +148,51 @@ static int32_t dop_tile_solve(Dev*, int32_t trans, const double* L, int64_t ld, 
     }
     return 0;
 }
-static int32_t dop_phase(Dev*, int) { return 0; }
+static int32_t dop_stream(Dev* dev, int which) {
+    dev->stream = which;
+    return 0;
+}
+static int32_t dop_link(Dev* dev, int from, int to) {
+    dev->trace.insert(dev->trace.end(), {-1, from, to});
+    return 0;
+}
+static int32_t dop_fork(Dev* dev) {
+    dev->stream = 0;
+    dev->trace.clear();
+    return 0;
+}
+static int32_t dop_join(Dev* dev) {
+    dev->stream = 0;
+    return 0;
+}
+static void dop_mark(Dev* dev, int code, int64_t k) { dev->trace.insert(dev->trace.end(), {code, k, dev->stream}); }
+static int32_t dop_bulk(Dev*, int) { return 0; }
+static int32_t dop_gather_tiles(Dev*, double* dst, int64_t ldd, int64_t dstep, const double* src, int64_t lds,
+                                int64_t sstep, int64_t count, int64_t nb, int64_t w, int64_t limit, int64_t lstep,
+                                int zero_pad) {
+    for (int64_t t = 0; t < count; ++t) {
+        int64_t rows = limit - t * lstep;
+        rows = rows < 0 ? 0 : (rows > nb ? nb : rows);
+        for (int64_t c = 0; c < w; ++c)
+            for (int64_t r = 0; r < (zero_pad ? nb : rows); ++r)
+                dst[t * dstep + r + c * ldd] = (r < rows) ? src[t * sstep + r + c * lds] : 0.0;
+    }
+    return 0;
+}
 static int32_t dop_nccl_bcast(Dev*, void*, double*, int64_t, int) { return MADQP_ERR_STATE; }
 static int32_t dop_nccl_reduce(Dev*, void*, double*, int64_t, int) { return MADQP_ERR_STATE; }
 static int32_t dop_nccl_allreduce(Dev*, void*, double*, int64_t) { return MADQP_ERR_STATE; }
+static int32_t dop_nccl_send(Dev*, void*, const double*, int64_t, int) { return MADQP_ERR_STATE; }
+static int32_t dop_nccl_recv(Dev*, void*, double*, int64_t, int) { return MADQP_ERR_STATE; }
+static int32_t dop_nccl_group(Dev*, int) { return MADQP_ERR_STATE; }
+static int32_t dop_group_pack(Dev*, double* out, const double* loc, int64_t I0, int64_t wg, int64_t nb, int64_t R,
+                              int64_t r) {
+    for (int64_t i = 0; i < wg; ++i) {
+        const int64_t I = I0 + i / nb;
+        out[i] = (I % R == r) ? loc[(I / R) * nb + i % nb] : 0.0;
+    }
+    return 0;
+}
 
 #include "../../madqp_jl_amd/csrc/dist_core.inc"
 
@@ -186,5 +231,11 @@ int32_t madqp_distcpu_solve(madqp_dist* d, double* rhs) { return distcore::solve
 int32_t madqp_distcpu_bytes_sent(madqp_dist* d, int64_t* b) {
     *b = d->bytes_sent;
     return 0;
+}
+// the recorded schedule of the last factorisation: returns the number of int64 entries (triples), copies up to cap
+int64_t madqp_distcpu_trace(madqp_dist* d, int64_t* out, int64_t cap) {
+    const std::vector<int64_t>& t = d->dev->trace;
+    for (int64_t i = 0; i < (int64_t)t.size() && i < cap; ++i) out[i] = t[(size_t)i];
+    return (int64_t)t.size();
 }
 }

@@ -52,6 +52,11 @@ def main():
     rc = lib.madqp_distcpu_factor(h, C.byref(info))
     assert rc == 0 and comm.error is None, (rc, comm.error)
     rec["spd_info"] = info.value
+    lib.madqp_distcpu_trace.restype = C.c_int64
+    cnt = lib.madqp_distcpu_trace(h, None, C.c_int64(0))
+    buf = (C.c_int64 * max(cnt, 1))()
+    lib.madqp_distcpu_trace(h, buf, C.c_int64(cnt))
+    rec["schedule"] = [list(buf[i:i + 3]) for i in range(0, cnt, 3)]  # (mark, k, stream) | (-1, from, to)
     L = np.linalg.cholesky(K)
     err = 0.0
     for I, J in tiles:
@@ -66,8 +71,10 @@ def main():
     # solves: replicated right-hand side in, replicated solution out
     b = rng.standard_normal(n)
     x = b.copy()
+    before = dict(comm.calls)
     rc = lib.madqp_distcpu_solve(h, x.ctypes.data_as(C.c_void_p))
     assert rc == 0 and comm.error is None, (rc, comm.error)
+    rec["solve_calls"] = {k: comm.calls[k] - before[k] for k in ("reduce", "bcast")}
     ref = np.linalg.solve(K, b)
     rec["solve_err"] = float(np.max(np.abs(x - ref)) / np.max(np.abs(ref)))
     rec["nan"] = bool(np.isnan(x).any())
