@@ -716,6 +716,8 @@ static int32_t dk_check(madqp_dkkt* k, const madqp_state* st) {
 static int32_t dk_At_partial(madqp_dkkt* k, double alpha, const double* u) {
     madqp_dist* d = k->d;
     if (!k->m) return MADQP_OK;
+    if (d->P == 1 && d->Q == 1)  // one rank owns every block, local order = global order: one product
+        return madqp_gemv_impl(k->ctx, 1, k->m, d->n, alpha, k->AI, k->ldai, u, 1.0, k->gn, MADQP_PROF_GEMV);
     for (int64_t li : k->own_li) {
         const int64_t I = li * d->P + d->p, w = distcore::tsize(d, I);
         int32_t r = madqp_gemv_impl(k->ctx, 1, k->m, w, alpha, k->AI + li * d->nb, k->ldai, u, 1.0, k->gn + I * d->nb,
@@ -727,6 +729,8 @@ static int32_t dk_At_partial(madqp_dkkt* k, double alpha, const double* u) {
 static int32_t dk_A_partial(madqp_dkkt* k, double alpha, const double* x) {
     madqp_dist* d = k->d;
     if (!k->m) return MADQP_OK;
+    if (d->P == 1 && d->Q == 1)
+        return madqp_gemv_impl(k->ctx, 0, k->m, d->n, alpha, k->AI, k->ldai, x, 1.0, k->gm, MADQP_PROF_GEMV);
     for (int64_t li : k->own_li) {
         const int64_t I = li * d->P + d->p, w = distcore::tsize(d, I);
         int32_t r = madqp_gemv_impl(k->ctx, 0, k->m, w, alpha, k->AI + li * d->nb, k->ldai, x + I * d->nb, 1.0, k->gm,

@@ -718,7 +718,11 @@ class MPCSolver:
         assert np.all(self.zl_r > 0.0) and np.all(self.zu_r > 0.0)  # :120-123
         assert np.all(self.x_lr > self.xl_r) and np.all(self.x_ur < self.xu_r)
 
-    def initialize(self):  # solver.jl:127-182
+    def initialize(self, start=None):  # solver.jl:127-182
+        """``start``: None = the reference's start point (init_starting_point, one factorisation + two solves); a dict
+        with x, y, zl, zu (scaled iterates of length n, m, n, n) = take these instead -- bench.py's cpu_baseline leg
+        times ONE iteration at the metric size from the start point the device computed (equal to this file's to 1e-9,
+        tests/test_gpu_solver.py) without paying a second 90 s factorisation for it."""
         qp, opt = self.qp, self.opt
         nx = self.nx
         # MadNLP.initialize!(cb, ...) (MadNLP-recall; :131-142)
@@ -756,7 +760,10 @@ class MPCSolver:
         self.eval_cons()  # :169
         self.norm_b = np.max(np.abs(self.rhs), initial=0.0)  # :173
         self.norm_c = np.max(np.abs(self.f), initial=0.0)  # :174
-        self.init_starting_point()  # :177
+        if start is None:
+            self.init_starting_point()  # :177
+        else:
+            self.x[:], self.y[:], self.zl[:], self.zu[:] = start["x"], start["y"], start["zl"], start["zu"]
         self.mu = opt.mu_init  # :179
 
     def affine_direction(self):  # solver.jl:188-192

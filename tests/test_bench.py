@@ -75,3 +75,24 @@ def test_last_resort_reporter_prints_the_held_line_only_when_the_bench_process_d
         out = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=60)
         lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
         assert len(lines) == 1 and json.loads(lines[0])["metric"] == expect, (mode, out.stdout, out.stderr)
+
+
+def test_watchdog_measures_silence_not_the_length_of_the_run():
+    """one fixed timeout around set-up + warm-up + all steps discards a healthy long run; the watchdog of the
+    shared-QP leg is re-armed by every sign of progress and fires only after `seconds` of silence."""
+    import time
+
+    fired = []
+    dog = bench.Watchdog(0.25, lambda: fired.append(time.perf_counter()))
+    t0 = time.perf_counter()
+    for _ in range(6):  # 0.6 s of "run", a kick every 0.1 s: longer than the timeout, never silent that long
+        time.sleep(0.1)
+        dog.kick()
+    assert not fired
+    time.sleep(0.5)  # silence
+    assert len(fired) == 1 and fired[0] - t0 >= 0.6 + 0.25 - 0.05
+    dog.stop()
+    dog = bench.Watchdog(0.2, lambda: fired.append(0))
+    dog.stop()
+    time.sleep(0.3)
+    assert len(fired) == 1
