@@ -275,6 +275,13 @@ int32_t madqp_kkt_solve(madqp_kkt* kkt, const madqp_state* st, double* w);
 /* MadNLP.mul!(w, kkt, v, alpha, beta) (src/KKT/normalkkt.jl:207-219), with H for a QP */
 int32_t madqp_kkt_mul(madqp_kkt* kkt, const madqp_state* st, double* w, const double* v,
                       double alpha, double beta);
+/* The same product for the residual check of solve_system! (src/linear_solver.jl:26-31: solve!(kkt, d), then
+ * mul!(w, kkt, d, -1, 1)): v must be the vector the LAST madqp_kkt_solve on this object returned, unmodified since.
+ * The condensed solve ends with A dx (its decondensation needs it); this call takes that product instead of streaming
+ * A a second time -- same kernel, same operands, bitwise the result of madqp_kkt_mul.  Other KKT forms, or a solve
+ * that left nothing to reuse: identical to madqp_kkt_mul. */
+int32_t madqp_kkt_mul_solved(madqp_kkt* kkt, const madqp_state* st, double* w, const double* v,
+                             double alpha, double beta);
 /* MadNLP.jtprod!(out, kkt, y) (src/KKT/normalkkt.jl:162-164): out(n) = [A' y ; -y[ind_ineq]] */
 int32_t madqp_kkt_jtprod(madqp_kkt* kkt, double* out, const double* y);
 /* model callbacks of the loop (src/solver.jl:166-169,338-340; formulas scripts/qp_gpu.jl:29-40):

@@ -129,6 +129,7 @@ _SIGNATURES = {
     "madqp_kkt_factorize": [vp, pi32],
     "madqp_kkt_solve": [vp, pstate, vp],
     "madqp_kkt_mul": [vp, pstate, vp, vp, f64, f64],
+    "madqp_kkt_mul_solved": [vp, pstate, vp, vp, f64, f64],
     "madqp_kkt_jtprod": [vp, vp, vp],
     "madqp_kkt_eval": [vp, pstate, vp, vp, f64, pf64],
     "madqp_kkt_matrix": [vp, C.POINTER(vp), pi64],

@@ -334,8 +334,9 @@ class HipBackend:
     def kkt_solve(self, h, st, w):
         self._ck(self.lib.madqp_kkt_solve(h, C.byref(st.cstruct), ptr(w)))
 
-    def kkt_mul(self, h, st, w, v, alpha, beta):
-        self._ck(self.lib.madqp_kkt_mul(h, C.byref(st.cstruct), ptr(w), ptr(v), alpha, beta))
+    def kkt_mul(self, h, st, w, v, alpha, beta, solved=False):
+        f = self.lib.madqp_kkt_mul_solved if solved else self.lib.madqp_kkt_mul
+        self._ck(f(h, C.byref(st.cstruct), ptr(w), ptr(v), alpha, beta))
 
     def kkt_jtprod(self, h, out, y):
         self._ck(self.lib.madqp_kkt_jtprod(h, ptr(out), ptr(y)))

@@ -776,117 +776,6 @@ __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     MID_STAMP(3);
 }
 
-// ---- small matrices in batches: the WHOLE factorisation of one problem in one workgroup -------------------------
-// Batches of small QPs (batch.hip, BASELINE configs[3]: 1024 x order 512) went through ~10 launches per factorisation,
-// every one of them over all problems: four rounds of the diagonal kernel (one workgroup per CU: it needs the CU's
-// LDS) with the matrix pipes idle, then panel and update launches whose tiles are a K = 128 product each between a DMA
-// prologue and a read-modify-write epilogue (2.9 ms per lock-step iteration of 1024 problems, 0.6 ms of MFMA work).
-// Here one 512-thread workgroup owns a problem from its first diagonal block to its last: right-looking over the
-// 128-column blocks,
-//   diagonal block  potf2_inv_body (block from global memory, L_kk and W_k = L_kk^-1 back to it),
-//   panel           L_ik = C_ik W_k'            two tiles at a time (waves 0-3 / 4-7, as chol_mid_step_kernel),
-//   trailing        C_ij -= L_ik L_jk'          two tiles at a time, accumulators start at -C_ij and are stored negated,
-// all products K = 128 through the GEMM core's LDS-DMA main loop.  What one phase writes and the next reads goes
-// through global memory inside ONE workgroup: ordered by the workgroup barrier (one CU, one L1).  A tile accumulates
-// its updates in the order k = 0, 1, ..: deterministic.  Needs the padded layout the batch allocates (leading
-// dimension >= order rounded up to 128, even, 16-byte aligned base; rows beyond n are zero and never written).
-struct SmallBatchArgs {
-    double* A;
-    int64_t lda, n, sA;
-    int32_t nblk;
-    double* winv;
-    int64_t sW;
-    int32_t* info;
-    const int32_t* skip;
-};
-
-__global__ __launch_bounds__(MID_THREADS) void chol_small_batched_kernel(SmallBatchArgs a) {
-    __shared__ __attribute__((aligned(16))) double smem[P2_S_DOUBLES + P2_WD_DOUBLES];
-    const int64_t b = blockIdx.x;
-    if (a.skip && a.skip[b] != 0) return;
-    double* A = a.A + b * a.sA;
-    double* winv = a.winv + b * a.sW;
-    int32_t* info = a.info + b;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2, w4 = wave & 3;
-    const int wi = w4 & 1, wj = w4 >> 1;
-    const int lo = lane & 15, hi = lane >> 4;
-    const int64_t npad = (int64_t)a.nblk * NB;
-    double* lds = smem + half * (4 * TILE_DOUBLES);
-    for (int k = 0; k < a.nblk; ++k) {
-        const int64_t c0 = (int64_t)k * NB;
-        const int nbk = (int)((a.n - c0 < NB) ? (a.n - c0) : NB);
-        double* Wcm = winv + (int64_t)k * WBLK;
-        potf2_inv_body(A + c0 + c0 * a.lda, a.lda, nbk, Wcm, Wcm + NB * NB, info, (int32_t)c0, smem, smem + P2_S_DOUBLES);
-        __syncthreads();  // L_kk and W_k are in global memory for this workgroup; the LDS image is free
-        const int rem = a.nblk - k - 1;  // block rows below
-        // phase 0, panel: L_ik = C_ik W_k' for the rem tiles below the block (in place: a tile is read to the end of K
-        // before it is stored); phase 1, trailing update: tile t = i'(i'+1)/2 + j' (0 <= j' <= i' < rem) is
-        // (k+1+i', k+1+j'), C_ij -= L_ik L_jk' with the accumulators starting at -C_ij.  One body for both.
-        for (int phase = 0; phase < 2; ++phase) {
-            const int ntask = phase ? rem * (rem + 1) / 2 : rem;
-            for (int t0 = 0; t0 < ntask; t0 += 2) {
-                const int t = t0 + half;
-                if (t >= ntask) {  // the other half has a tile: keep its barriers company
-                    for (int q = 0; q < MID_BARRIERS; ++q) __builtin_amdgcn_s_barrier();
-                    continue;
-                }
-                int ip = t, jp = -1;
-                if (phase) {
-                    ip = (int)((sqrtf(1.0f + 8.0f * (float)t) - 1.0f) * 0.5f);
-                    while (ip * (ip + 1) / 2 > t) --ip;
-                    while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
-                    jp = t - ip * (ip + 1) / 2;
-                }
-                ip = __builtin_amdgcn_readfirstlane(ip);
-                jp = __builtin_amdgcn_readfirstlane(jp);
-                const int64_t i0 = (int64_t)(k + 1 + ip) * NB;
-                const int64_t jc0 = (int64_t)(k + 1 + jp) * NB;  // output columns (phase 0: block k itself)
-                GemmArgs g{};
-                g.X = A + c0 * a.lda;
-                g.ldx = a.lda;
-                g.Y = phase ? g.X : Wcm;  // phase 0: Y[j + kk*NB] = W(j, kk)
-                g.ldy = phase ? a.lda : NB;
-                g.M = a.n;
-                g.N = phase ? a.n : NB;
-                g.Mread = npad;
-                g.Nread = phase ? npad : NB;
-                g.K = NB;
-                double4_t acc[4][4];
-#pragma unroll
-                for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-                    for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            double x = 0.0;
-                            if (phase) {
-                                int64_t gj = jc0 + wj * 64 + tj * 16 + hi + 4 * v;
-                                gj = (gj < a.n) ? gj : a.n - 1;  // columns beyond n: any value will do, no branch
-                                x = -A[i0 + wi * 64 + ti * 16 + lo + gj * a.lda];
-                            }
-                            acc[ti][tj][v] = x;
-                        }
-                mainloop_dma(g, i0, phase ? jc0 : 0, lds, wi, wj, lane, w4, acc);
-                const double sgn = phase ? -1.0 : 1.0;
-#pragma unroll
-                for (int ti = 0; ti < 4; ++ti) {
-                    const int64_t gi = i0 + wi * 64 + ti * 16 + lo;
-#pragma unroll
-                    for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int64_t gj = jc0 + wj * 64 + tj * 16 + hi + 4 * v;
-                            if (gi < a.n && gj < a.n && gi >= gj) A[gi + gj * a.lda] = sgn * acc[ti][tj][v];
-                        }
-                }
-            }
-            __syncthreads();  // the panel is complete before anybody multiplies with it
-        }
-        __syncthreads();  // the trailing matrix carries step k before the next diagonal block is read
-    }
-}
 }  // namespace
 
 extern "C" int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out) {
@@ -1279,17 +1168,6 @@ int32_t madqp_chol_factor_batched(madqp_ctx* ctx, double* A, int64_t lda, int64_
     ARG_TRY(ctx, A && winv && info && lda >= n && B >= 1);
     if (n == 0) return MADQP_OK;
     HIP_TRY(ctx, hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), ctx->stream));
-    // small matrices in the padded layout: one workgroup per problem, one launch (chol_small_batched_kernel);
-    // MADQP_CHOL_SMALL_MAX: largest order for it (0 = the launch-per-step schedule below)
-    static const int64_t small_max = getenv("MADQP_CHOL_SMALL_MAX") ? atoll(getenv("MADQP_CHOL_SMALL_MAX")) : 2048;
-    const int64_t npad = (n + NB - 1) / NB * NB;
-    if (n <= small_max && lda >= npad && lda % 2 == 0 && (((uintptr_t)A) & 15) == 0 && sA % 2 == 0 && B <= 0x7fffffff) {
-        ProfScope ps(ctx, MADQP_PROF_POTRF_GEMM);
-        hipLaunchKernelGGL(chol_small_batched_kernel, dim3((unsigned)B), dim3(MID_THREADS), 0, ctx->stream,
-                           SmallBatchArgs{A, lda, n, sA, (int32_t)(npad / NB), winv, sW, info, skip});
-        LAUNCH_CHECK(ctx);
-        return MADQP_OK;
-    }
     CholBatch c{ctx, A, lda, n, sA, winv, sW, info, B, skip};
     return bfactor_range(c, 0, n);
 }

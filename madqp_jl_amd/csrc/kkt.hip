@@ -57,6 +57,7 @@ struct madqp_kkt {
     double* K;
     int64_t ldk;
     double *theta, *t, *u;  // m
+    const double* u_is_A_of;  // condensed mode: u = A x for the primal part of this vector (the last solve's), or nullptr
     int64_t np;             // augmented mode: nx rounded up to a multiple of 128 = row of the first constraint
     double* b;              // augmented mode: right-hand side of order np + m
     int scaled;             // augmented mode: K2.5 (see the header comment)
@@ -566,6 +567,7 @@ extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* 
     if (r) return r;
     madqp_ctx* ctx = k->ctx;
     ARG_TRY(ctx, w != nullptr);
+    k->u_is_A_of = nullptr;
     double* wx = w;
     double* wy = w + st->n;
     if (k->scaled) {  // r1 = p_x + p_zl / l_diag + p_zu / u_diag (signs of src/kernels.jl:157-158)
@@ -629,7 +631,9 @@ extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* 
         KLAUNCH(decondense_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, k->theta, k->t, k->u,
                 wx, wy);
     }
-    return madqp_finish_aug_solve(ctx, st, w);
+    if ((r = madqp_finish_aug_solve(ctx, st, w))) return r;
+    if (k->m) k->u_is_A_of = w;  // dx is final since the sweeps: u = A dx (madqp_kkt_mul_solved)
+    return MADQP_OK;
 }
 
 extern "C" int32_t madqp_kkt_jtprod(madqp_kkt* k, double* out, const double* y) {
@@ -645,13 +649,25 @@ extern "C" int32_t madqp_kkt_jtprod(madqp_kkt* k, double* out, const double* y) 
     return MADQP_OK;
 }
 
+static int32_t kkt_mul_impl(madqp_kkt* k, const madqp_state* st, double* w, const double* v, double alpha, double beta,
+                            bool v_is_last_solution);
 extern "C" int32_t madqp_kkt_mul(madqp_kkt* k, const madqp_state* st, double* w, const double* v,
                                  double alpha, double beta) {
+    return kkt_mul_impl(k, st, w, v, alpha, beta, false);
+}
+extern "C" int32_t madqp_kkt_mul_solved(madqp_kkt* k, const madqp_state* st, double* w, const double* v,
+                                        double alpha, double beta) {
+    return kkt_mul_impl(k, st, w, v, alpha, beta, true);
+}
+static int32_t kkt_mul_impl(madqp_kkt* k, const madqp_state* st, double* w, const double* v, double alpha, double beta,
+                            bool v_is_last_solution) {
     int32_t r = check_kkt_state(k, st);
     if (r) return r;
     madqp_ctx* ctx = k->ctx;
     ARG_TRY(ctx, w && v);
     const int64_t nx = k->nx, n = st->n;
+    const bool have_Av = v_is_last_solution && k->m && k->u_is_A_of == v;  // the solve's own A dx, same kernel and operands
+    k->u_is_A_of = nullptr;
     // wx = alpha A_full' vy + beta wx  (+ alpha H vx)
     if ((r = apply_At(k, alpha, v + n, beta, w))) return r;
     if (k->H && nx)
@@ -667,7 +683,7 @@ extern "C" int32_t madqp_kkt_mul(madqp_kkt* k, const madqp_state* st, double* w,
     }
     // wy = alpha A_full vx + beta wy
     if (k->m) {
-        if ((r = apply_A(k, 1.0, v, 0.0, k->u))) return r;
+        if (!have_Av && (r = apply_A(k, 1.0, v, 0.0, k->u))) return r;
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(mul_rows_kernel, k->m, k->m, k->d_slot, k->u, v + nx, w + n, alpha, beta);
     }

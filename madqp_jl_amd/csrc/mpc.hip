@@ -93,7 +93,7 @@ int32_t solve_system(madqp_mpc* s) {
     TRY(madqp_copy(s->ctx, len, s->st.p, s->st.d));
     TRY(madqp_kkt_solve(s->kkt, &s->st, s->st.d));
     TRY(madqp_copy(s->ctx, len, s->st.p, s->w1));
-    TRY(madqp_kkt_mul(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));
+    TRY(madqp_kkt_mul_solved(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));  // d: the solve's result, untouched
     for (int32_t it = 0; it < s->opt.refine_steps; ++it) {  // extension (off by default): d += K^-1 (p - K d)
         TRY(madqp_kkt_solve(s->kkt, &s->st, s->w1));
         TRY(madqp_axpy(s->ctx, len, 1.0, s->w1, s->st.d));
@@ -373,7 +373,7 @@ int32_t solve_system_queue(madqp_mpc* s, int slot0) {
     TRY(madqp_copy(s->ctx, len, s->st.p, s->st.d));
     TRY(madqp_kkt_solve(s->kkt, &s->st, s->st.d));
     TRY(madqp_copy(s->ctx, len, s->st.p, s->w1));
-    TRY(madqp_kkt_mul(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));
+    TRY(madqp_kkt_mul_solved(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));
     return madqp_q_norm_inf3(s->ctx, len, s->w1, s->st.p, s->st.d, slot0);
 }
 int32_t residual_verdict(madqp_mpc* s, const double* nrm) {  // src/linear_solver.jl:36-43

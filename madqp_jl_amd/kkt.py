@@ -132,6 +132,13 @@ class HIPCondensedKKTSystem:
         self.be.kkt_mul(self._h, self.st, w, v, alpha, beta)
         return w
 
+    def mul_solved(self, w, v, alpha=1.0, beta=0.0):
+        """``mul`` for the residual check of solve_system! (src/linear_solver.jl:26-31): ``v`` is what the last
+        ``solve`` returned, unmodified -- the condensed solve's own ``A dx`` is taken instead of a second pass over A
+        (``madqp_kkt_mul_solved``: bitwise the result of ``mul``)."""
+        self.be.kkt_mul(self._h, self.st, w, v, alpha, beta, solved=True)
+        return w
+
     def eval_model(self, q, rhs, c0) -> float:
         """obj / grad! / cons! callbacks of the loop (src/solver.jl:166-169, 338-340)."""
         return self.be.kkt_eval(self._h, self.st, q, rhs, c0)

@@ -215,7 +215,7 @@ class MPCSolver:
         be.copy(st.p, st.d)
         self.kkt.solve(st.d)
         be.copy(st.p, st.w1)
-        self.kkt.mul(st.w1, st.d, -1.0, 1.0)
+        getattr(self.kkt, "mul_solved", self.kkt.mul)(st.w1, st.d, -1.0, 1.0)  # d is the solve's result, untouched
         for _ in range(self.opt.refine_steps):  # extension, off by default: d += K^-1 (p - K d)
             self.kkt.solve(st.w1)
             be.axpy(1.0, st.w1, st.d)

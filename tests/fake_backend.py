@@ -393,7 +393,7 @@ class FakeBackend:
         o[: h.nx] = h.A.T @ yy
         o[h.nx:] = -yy[h.ind_ineq]
 
-    def kkt_mul(self, h, st, w, v, alpha, beta):
+    def kkt_mul(self, h, st, w, v, alpha, beta, solved=False):
         wx, wy, _, _ = self._parts(st, w)
         vx, vy, _, _ = self._parts(st, v)
         nx = h.nx

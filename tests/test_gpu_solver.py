@@ -158,6 +158,16 @@ def test_kkt_system_conformance(hip, with_eq):
     st.p.copy_(torch.as_tensor(b))
     be.copy(st.p, st.d)
     s.kkt.solve(st.d)
+    be.fill(0.0, st.w2)
+    s.kkt.mul_solved(st.w2, st.d, 1.0, 0.0)  # the solve's own A dx instead of a second pass over A:
+    be.fill(0.0, st.w1)
+    s.kkt.mul(st.w1, st.d, 1.0, 0.0)
+    assert torch.equal(st.w1, st.w2)         # bitwise the generic product
+    be.fill(0.0, st.w2)
+    s.kkt.mul_solved(st.w2, st.p, 1.0, 0.0)  # a vector that is NOT the last solution: the product is computed
+    be.fill(0.0, st.w1)
+    s.kkt.mul(st.w1, st.p, 1.0, 0.0)
+    assert torch.equal(st.w1, st.w2)
     be.fill(0.0, st.w1)
     s.kkt.mul(st.w1, st.d, 1.0, 0.0)
     res = np.max(np.abs(st.w1.cpu().numpy() - b)) / max(1.0, np.max(np.abs(b)))
