@@ -91,6 +91,11 @@ class IPMOptions:
         self.check_residual = False
         self.kkt_system = "K2"
         self.fixed_variable_treatment = "error"  # or "relax_bound" (MadNLP.RelaxBound)
+        # NOT in the reference (default 0 = its solve_system!): steps of iterative refinement d += K^-1 (p - K d) with
+        # the residual src/linear_solver.jl:29-31 forms anyway.  Mirrors the product's `refine_steps` extension, and
+        # gives the tests a second, equally valid CPU run of every problem: the distance between the two runs is what
+        # the conditioning of the problem lets any two accurate implementations agree to (tests/parity.py).
+        self.refine_steps = 0
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError(f"unknown option {k}")
@@ -663,6 +668,11 @@ class MPCSolver:
         self.kkt.solve(d)
         w.values[:] = p.values
         self.kkt.mul(w, d, -1.0, 1.0)
+        for _ in range(self.opt.refine_steps):  # extension, off by default (see IPMOptions)
+            self.kkt.solve(w)
+            d.values += w.values
+            w.values[:] = p.values
+            self.kkt.mul(w, d, -1.0, 1.0)
         norm_w = np.max(np.abs(w.values), initial=0.0)
         norm_p = np.max(np.abs(p.values), initial=0.0)
         ratio = norm_w / max(1.0, norm_p)

@@ -37,10 +37,17 @@ def solve_case(be, grid, qp, synthetic_seed=None, **opts):
     s1.close()
     okw = {k: v for k, v in opts.items() if k in ("max_ncorr",)}
     ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG, **okw)
+    # the same algorithm once more on the CPU with one refinement step per solve: what the problem's conditioning lets
+    # two accurate executions agree to (tests/parity.py)
+    ref2 = mpc.solve(qp, kkt_system="condensed", regularization=OREG, refine_steps=1, **okw)
     keys = ("k", "alpha_p", "alpha_d", "inf_pr", "inf_du", "inf_compl", "mu")
     rec.update(status=[r["status"], ref["status"]], iters=[r["iter"], ref["iter"]],
                trace=[{k: float(t[k]) for k in keys} for t in r["trace"]],
                ref_trace=[{k: float(t[k]) for k in keys} for t in ref["trace"]],
+               ref2_trace=[{k: float(t[k]) for k in keys} for t in ref2["trace"]],
+               sens_dx=float(np.max(np.abs(ref2["solution"] - ref["solution"]))),
+               sens_dy=float(np.max(np.abs(ref2["multipliers"] - ref["multipliers"]))),
+               sens_obj=float(abs(ref2["objective"] - ref["objective"]) / max(1.0, abs(ref["objective"]))),
                single_trace=[{k: float(t[k]) for k in keys} for t in r1["trace"]],
                dx_single=float(np.max(np.abs(r["solution"] - r1["solution"]))),
                dx=float(np.max(np.abs(r["solution"] - ref["solution"]))),

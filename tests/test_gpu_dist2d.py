@@ -47,28 +47,25 @@ def test_grid_on_one_gpu(tmp_path, P, Q, n, nb, port):
 
 
 def check_kkt_records(recs):
-    close = lambda a, b, tol: abs(a - b) <= tol * max(1.0, abs(a), abs(b))
+    """Stated bar: identical iteration count, per-iteration quantities to 1e-9 while mu >= 1e-4 and 1e-6
+    after, |dx| <= 1e-7, objective to 1e-9 -- loosened nowhere by hand: where the conditioning of a case does not
+    support the bar (the condensed LP near convergence, the rows scaled by 40, the equality rows at Theta = 1e8), the
+    tolerance is 4 x the distance between two CPU runs of the oracle, LAPACK solves with and without one refinement
+    step (tests/parity.py; round 2 had 1e-5, x100 and +-1 iteration here)."""
+    from parity import SENS_FACTOR, close, compare_traces_measured
+
     for rec in recs:
         assert rec["qp_900_350"]["pieces_equal"]
         for name in ("qp_900_350", "qp_gondzio", "lp", "qp_eq", "qp_scaled_rows"):
             c = rec[name]
             assert c["status"] == [1, 1], (name, c["status"])
-            if name == "qp_eq":  # Theta = 1e8: the 2e-7 floor of the condensed form (test_kkt_system_conformance)
-                assert abs(c["iters"][0] - c["iters"][1]) <= 1 and c["dx"] <= 1e-5
-                continue
             assert c["iters"][0] == c["iters"][1], (name, c["iters"])
-            assert len(c["trace"]) == len(c["single_trace"]) and c["dx_single"] <= 1e-7  # also == the one-GPU path
-            for t, g, s1 in zip(c["trace"], c["ref_trace"], c["single_trace"]):
-                tol = 1e-9 if min(t["mu"], g["mu"]) >= 1e-4 else 1e-6
-                if name == "qp_scaled_rows":
-                    tol *= 100.0  # rows of A of very different magnitude: the one-GPU path is as far from the oracle
-                if name == "lp" and tol == 1e-6:
-                    tol = 1e-5  # an LP through the condensed form near convergence: K = dw I + A' Theta A sits at the
-                    # edge of fp64 (tests/parity.py); the one-GPU path (s1) differs from the oracle by as much
-                for key in ("alpha_p", "alpha_d", "inf_pr", "inf_du", "inf_compl", "mu"):
-                    assert close(t[key], g[key], tol), (name, t["k"], key, t[key], g[key], s1[key])
-            assert c["dx"] <= 1e-7 and c["dy"] <= 1e-6 and close(c["obj"][0], c["obj"][1], 1e-9), (name, c["dx"], c["dy"])
-            assert c["resid"] < 1e-7
+            assert len(c["trace"]) == len(c["single_trace"]) and c["dx_single"] <= max(1e-7, SENS_FACTOR * c["sens_dx"])
+            compare_traces_measured(c["trace"], c["ref_trace"], c["ref2_trace"], name)
+            assert c["dx"] <= max(1e-7, SENS_FACTOR * c["sens_dx"]), (name, c["dx"], c["sens_dx"])
+            assert c["dy"] <= max(1e-6, SENS_FACTOR * c["sens_dy"]), (name, c["dy"], c["sens_dy"])
+            assert abs(c["obj"][0] - c["obj"][1]) <= max(1e-9, SENS_FACTOR * c["sens_obj"]) * max(1.0, abs(c["obj"][1])), name
+            assert c["resid"] < 1e-7 or name == "qp_eq"  # (Theta = 1e8: the formulation's floor, test_kkt_system_conformance)
     for name in ("qp_900_350", "qp_gondzio", "lp", "qp_eq", "qp_scaled_rows"):  # replicated state: bitwise equal ranks
         assert all(rec[name]["trace"] == recs[0][name]["trace"] and rec[name]["xsum"] == recs[0][name]["xsum"]
                    for rec in recs), name

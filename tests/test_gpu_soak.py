@@ -3,7 +3,10 @@
 `seed0 = 9000` replays the stretch that contains seed 9195 (n_x = 186, m = 78, LP through the condensed form), the
 example DESIGN.md gave for "one iteration more than the oracle"; `seed0 = 1000` is the soak's default start.  Every
 problem runs through the Python driver, the native driver and the batched engine against the oracle with the
-acceptance rule of tests/parity.py: identical iteration counts, except threshold ties, which are counted and bounded.
+acceptance rule of tests/parity.py: identical iteration counts, except threshold ties -- LPs only, counted and bounded --
+objective to 1e-9 (relative) and solution to 1e-7 (the stated bar), or 4 x the distance between two CPU
+runs of the oracle (LAPACK solves with / without one refinement step) where the problem's conditioning does not support
+the bar (round 2 had 1e-7 / 1e-5 for every problem here).
 """
 import numpy as np
 import pytest
@@ -11,7 +14,7 @@ import pytest
 import madqp_jl_amd as M
 from oracle import mpc
 from oracle import qp as Q
-from parity import iteration_parity
+from parity import SENS_FACTOR, iteration_parity
 
 pytestmark = pytest.mark.gpu
 REG, OREG = M.FixedRegularization(1e-8, -1e-8), mpc.FixedRegularization(1e-8, -1e-8)
@@ -31,6 +34,9 @@ def soak_cases(seed0, count, only_lp=False):
 def run_case(hip, seed, n, m, lp, drivers):
     qp = Q.random_qp(seed, n, m, lp)
     ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG)
+    ref2 = mpc.solve(qp, kkt_system="condensed", regularization=OREG, refine_steps=1)  # tests/parity.py
+    sens_obj = abs(ref2["objective"] - ref["objective"]) / max(1.0, abs(ref["objective"]))
+    sens_x = float(np.max(np.abs(ref2["solution"] - ref["solution"]), initial=0.0)) if ref2["iter"] == ref["iter"] else np.inf
     dq = M.DeviceQP.from_numpy(hip.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
     ties = []
     for name in drivers:
@@ -50,12 +56,16 @@ def run_case(hip, seed, n, m, lp, drivers):
         assert r["status"] == ref["status"], (what, r["status"], ref["status"])
         if ref["status"] != M.SOLVE_SUCCEEDED:
             continue
-        tie = iteration_parity(r, ref, 1e-8, what) == "tie"
+        tie = iteration_parity(r, ref, 1e-8, what, lp=lp) == "tie"
         if tie:
             ties.append((what, r["iter"], ref["iter"]))
-        assert abs(r["objective"] - ref["objective"]) <= 1e-7 * max(1.0, abs(ref["objective"])), what
-        if not tie:  # after a tie the two points are different iterates (both satisfy the termination test)
-            assert np.max(np.abs(r["solution"] - ref["solution"]), initial=0.0) <= 1e-5, what
+        # after a tie the two points are different iterates, both of which satisfy the termination test to 1e-8
+        otol = 1e-7 if tie else max(1e-9, SENS_FACTOR * sens_obj)
+        dobj = abs(r["objective"] - ref["objective"]) / max(1.0, abs(ref["objective"]))
+        assert dobj <= otol, (what, "objective", dobj, otol)
+        if not tie and np.isfinite(sens_x):
+            dx = np.max(np.abs(r["solution"] - ref["solution"]), initial=0.0)
+            assert dx <= max(1e-7, SENS_FACTOR * sens_x), (what, "solution", dx, sens_x)
     return ties
 
 
@@ -72,7 +82,7 @@ def test_seed_9195_condensed_lp(hip):
         r = s.solve()
         s.close()
         assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
-        tie = iteration_parity(r, ref, 1e-8, driver) == "tie"
+        tie = iteration_parity(r, ref, 1e-8, driver, lp=True) == "tie"
         assert abs(r["objective"] - ref["objective"]) <= (1e-7 if tie else 1e-9) * max(1.0, abs(ref["objective"]))
         if not tie:
             assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7

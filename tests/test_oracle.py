@@ -244,3 +244,31 @@ def test_k25_equals_k2(make):
     assert abs(k2["objective"] - k25["objective"]) <= 1e-6
     for key in ("solution", "constraints", "multipliers"):
         assert np.max(np.abs(k2[key] - k25[key])) <= 1e-6
+
+
+def test_seed_9195_two_hosts_is_a_threshold_tie():
+    """DESIGN.md section 4 / tests/parity.py: on soak seed 9195 (LP through the condensed form) the oracle does not agree
+    with itself -- 12 iterations on the GPU box's host CPU, 13 in the build container.  Both traces are committed
+    (tests/golden/make_seed9195.py, one run per host), so the claim is checkable here: the same path up to iteration
+    11 to the accuracy the conditioning leaves -- the two LAPACK builds are 3.5e-7 apart at the START POINT already and
+    6.2e-5 at iteration 10, on identical inputs with identical software: K = delta_w I + A' Theta A without a Hessian
+    sits at the edge of fp64 -- and at iteration 12 one run is under the termination threshold while the other misses
+    it by less than a factor 4: the definition of a threshold tie.  This host must reproduce one of the two."""
+    import json
+    import os
+
+    from parity import TIE_FACTOR, worst_residual
+
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    a = json.load(open(os.path.join(g, "seed9195_oracle_gpu_box_host.json")))
+    b = json.load(open(os.path.join(g, "seed9195_oracle_build_container.json")))
+    assert a["host"]["cpu"] != b["host"]["cpu"] and a["host"]["scipy"] == b["host"]["scipy"]  # same software, other CPU
+    assert (a["status"], b["status"]) == (1, 1) and (a["iter"], b["iter"]) == (12, 13)
+    for ta, tb in zip(a["trace"][:12], b["trace"][:12]):  # the same path until the deciding iteration
+        for k in ("inf_pr", "inf_du", "inf_compl", "mu", "alpha_p", "alpha_d"):
+            assert abs(ta[k] - tb[k]) <= 1e-4 * max(1.0, abs(tb[k])), (ta["k"], k)
+    wa, wb = worst_residual(a["trace"][12]), worst_residual(b["trace"][12])
+    assert wa <= 1e-8 < wb <= TIE_FACTOR * 1e-8, (wa, wb)
+    assert abs(a["objective"] - b["objective"]) <= 1e-7 * max(1.0, abs(b["objective"]))
+    here = mpc.solve(Q.random_qp(9195, 186, 78, True), kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8))
+    assert here["status"] == 1 and here["iter"] in (12, 13)
