@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--extra-timeout", type=float, default=240.0,
                    help="N > 1: seconds after which the shared-QP leg is given up (watchdog, exit code 3)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-batch-extra", action="store_true",
+                   help="skip the BASELINE configs[3] measurement (1024 x (512, 256) batch, a few seconds) in `extras`")
     p.add_argument("--no-kernel-timers", action="store_true",
                    help="do not time the MFMA kernel classes with event pairs (roofline.achieved is then 0): the "
                         "pure throughput of small problems, whose factorisation is replayed as a hipGraph only when "
@@ -301,6 +303,26 @@ def hbm_traffic(which, nx, m):
         except Exception:
             continue
     return None
+
+
+def batch_extra(M, be, seed):
+    """BASELINE configs[3] on this GPU, beside the headline: 1024 independent QPs (n_x = 512, m = 256) through the
+    lock-step batched engine (csrc/batch.hip) -- QP/s (set-up, all iterations and the read-back inside the timed region,
+    median of three solves after a full-size warm-up) and where that stands against the two bounds of the chip
+    (tools/bench_batch.py: batch_roofline)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_batch
+
+        dt, res, times = bench_batch.run_batched(M, be, 1024, 512, 256, seed + 2)
+        iters = sum(r["iter"] for r in res)
+        return {"metric": "independent QPs solved per second", "value": 1024 / dt, "unit": "QP/s", "seconds": dt,
+                "ipm_iterations_per_s": iters / dt, "solved": sum(r["status"] == M.SOLVE_SUCCEEDED for r in res),
+                "lock_step_iterations": int(max(r["iter"] for r in res)), "all_seconds": times,
+                "roofline": bench_batch.batch_roofline(512, 256, iters, dt),
+                "profile": "profiles/r03_batch1024_* (kernel stats, FETCH_SIZE / WRITE_SIZE)"}
+    except Exception as e:  # the headline must not depend on it
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def dist_setup(backend="nccl", share_device=False):
@@ -657,6 +679,8 @@ def main():
             out = bench_line(args, res, world)
         if mode == "local" and not args.no_second_ncorr:
             second_ncorr()
+        if rank == 0 and world == 1 and mode == "local" and not args.no_batch_extra:
+            out["extras"] = {"batch_1024x512x256": batch_extra(M, be, args.seed)}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, nx, m, M, be)
         if rank == 0:

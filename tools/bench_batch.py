@@ -17,6 +17,46 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
+def batch_roofline(nx, m, iters, seconds, max_ncorr=0):
+    """Where a batch of small QPs stands against the chip's two bounds (whole-run averages).
+    MFMA flops per problem-iteration: assembly m nx^2 + Cholesky nx^3/3.
+    Algorithmic HBM bytes per problem-iteration: every matrix pass the iteration needs at 8 B per entry, a pass over a
+    triangle counted as half a matrix -- per solve_system (two at max_ncorr = 0): A' u, A dx, A' v_y (m nx each; the
+    residual check reuses the solve's A dx), H v (nx^2), two sweeps over L (nx^2/2 each); per iteration besides:
+    jtprod A' y (m nx), the model evaluation H x + A x (nx^2 + m nx); assembly: H lower (nx^2/2) in, the scaled operand
+    sqrt(Theta) A written and read (2 m nx), K lower out (nx^2/2); Cholesky: K in, L out (nx^2/2 each)."""
+    flops = m * nx * nx + nx ** 3 / 3.0
+    solves = 2 + max_ncorr
+    doubles = solves * (3 * m * nx + nx * nx + nx * nx) + (m * nx) + (nx * nx + m * nx) + (nx * nx // 2 + 2 * m * nx + nx * nx // 2) + nx * nx
+    it_per_s = iters / seconds
+    tf, gbs = it_per_s * flops * 1e-12, it_per_s * 8.0 * doubles * 1e-9
+    return {"flops_per_problem_iteration": flops, "algorithmic_bytes_per_problem_iteration": 8.0 * doubles,
+            "achieved_TFLOPs": tf, "frac_of_fp64_mfma_peak": tf / bench.PEAK_F64_MFMA_TFLOPS,
+            "achieved_GBps_algorithmic": gbs, "frac_of_hbm_peak": gbs / bench.PEAK_HBM_GBS}
+
+
+def run_batched(M, be, batch, nx, m, seed, repeats=3, check_every=2, profile=False):
+    """The lock-step batched engine on `batch` synthetic QPs of this rank: (median seconds, results, all times)."""
+    import torch
+
+    opts = dict(max_iter=300, step_rule=M.AdaptiveStep(0.995), regularization=M.FixedRegularization(1e-8, -1e-8),
+                mu_min=1e-12)
+    qps = [M.DeviceQP.synthetic(be, seed + i, nx, m) for i in range(batch)]
+    warm = M.BatchedMPCSolver(qps, be, **opts)
+    warm.solve(check_every=check_every)
+    warm.close()
+    times, res = [], None
+    for _ in range(max(1, repeats)):
+        solver = M.BatchedMPCSolver(qps, be, **opts)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = solver.solve(check_every=check_every)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        solver.close()
+    return sorted(times)[len(times) // 2], res, times
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--batch", type=int, default=128)
@@ -87,6 +127,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "independent QPs solved per second", "value": a.batch / dt, "unit": "QP/s",
                           "ipm_iterations_per_s": iters / dt, "n_gpus": world, "batch": a.batch,
+                          "roofline": batch_roofline(a.nx, a.m, iters, dt),
                           "solved": ok, "config": {"workload": f"{a.batch} x synthetic dense QP nx={a.nx} m={a.m}",
                                                    "engine": a.engine, "streams_per_gpu": a.streams if a.engine == "streams" else None,
                                                    "lock_step_iterations": lockstep}, "seconds": dt,
