@@ -44,14 +44,14 @@ def parse():
     p.add_argument("--seed", type=int, default=20250614 + 1)
     p.add_argument("--driver", choices=("native", "python"), default="native",
                    help="host driver of the loop body: csrc/mpc.hip (one C call per iteration) or solver.py")
-    p.add_argument("--kkt", choices=("local", "distributed", "panels"), default=None,
+    p.add_argument("--kkt", choices=("local", "distributed"), default=None,
                    help="local: every GPU solves its own QP (weak scaling); distributed: all GPUs share ONE QP on a "
-                        "P x Q grid -- 2-D block-cyclic distributed Cholesky over RCCL (strong scaling); panels: round "
-                        "1's 1 x N layout.  Default: local on one GPU, distributed on several")
+                        "P x Q grid -- 2-D block-cyclic distributed Cholesky over RCCL (strong scaling).  Default: "
+                        "local on one GPU, distributed on several")
     p.add_argument("--kkt-system", choices=("condensed", "augmented"), default="condensed",
                    help="condensed (headline): K = H + Sigma_x + A' Theta A, Cholesky; augmented: the K2 form "
                         "[H + Sigma_x, A'; A, -D], L diag(I,-I) L' (reported with its own flop count)")
-    p.add_argument("--panel-width", type=int, default=None, help="tile size nb of --kkt distributed (panel width of --kkt panels)")
+    p.add_argument("--panel-width", type=int, default=None, help="tile size nb of --kkt distributed")
     p.add_argument("--no-independent-leg", action="store_true",
                    help="N > 1: skip the additional measurement of one independent QP per GPU")
     p.add_argument("--extra-timeout", type=float, default=240.0,
@@ -412,7 +412,7 @@ class StepLoop:
 def measure(args, M, be, world, seed, mode, max_ncorr=None, steps=None, warmup=None, progress=lambda: None):
     """Warm-up + the timed region (barrier / sync on both sides, MAX over ranks) for one solver set-up.
     mode "local": this rank's own QP; "grid": ONE QP over all ranks on a P x Q grid (madqp_dist_* / madqp_dkkt_*,
-    SURVEY.md 8e); "panels": round 1's 1 x N panel-cyclic layout with replicated H, A and a gathered factor (dist.py)."""
+    SURVEY.md 8e)."""
     import torch
 
     nx, m = args.nx, args.m
@@ -433,8 +433,7 @@ def measure(args, M, be, world, seed, mode, max_ncorr=None, steps=None, warmup=N
     # options of scripts/benchmarks_cpu.jl:35-44 (kkt_system -> condensed, linear_solver -> HIP Cholesky)
     solver = M.MPCSolver(dq, be, max_iter=300, step_rule=M.AdaptiveStep(0.995),
                          regularization=M.FixedRegularization(1e-8, -1e-8), mu_min=1e-12,
-                         max_ncorr=max_ncorr, scaling=True, distributed=(mode == "panels"),
-                         panel_width=args.panel_width if mode == "panels" else None,
+                         max_ncorr=max_ncorr, scaling=True,
                          driver=args.driver if mode == "local" else "python", kkt_system=args.kkt_system)
     progress()
     solver.initialize()
@@ -462,9 +461,6 @@ def measure(args, M, be, world, seed, mode, max_ncorr=None, steps=None, warmup=N
                nfact=loop.factorizations(), reinits=loop.reinits, steps=steps, warmup=warmup, k=solver.k,
                last_trace={k: solver.trace[-1][k] for k in ("k", "inf_pr", "inf_du", "inf_compl", "mu")}
                if solver.trace else None)
-    if mode == "panels":
-        res["layout"] = dict(kind="1 x N panel-cyclic, replicated H and A, gathered factor", panel_width=solver.kkt.panel_width,
-                             panels=len(solver.kkt.dchol.panels), bytes_broadcast_by_rank0=solver.kkt.dchol.bytes_sent)
     if mode == "grid":
         mem = 8 * (grid.ld * grid.ncp * (2 if dq.H is not None else 1) + dq.A_I.numel() + 2 * dq.A_J.numel())
         res["layout"] = dict(kind="P x Q block-cyclic, nothing of order n^2 or m n replicated", grid=[grid.P, grid.Q],
@@ -497,10 +493,8 @@ def bench_line(args, res, world):
         traffic, traffic_src = None, None
     what = {"local": "one independent QP per GPU",
             "grid": "ONE QP shared by all GPUs: 2-D block-cyclic distributed assembly + Cholesky + solves over RCCL "
-                    "(csrc/dist.hip)",
-            "panels": "ONE QP shared by all GPUs: 1 x N panel-cyclic Cholesky, replicated operands (dist.py)"}[mode]
-    par = "independent" if mode == "local" else (
-        "grid %dx%d nb=%d" % (*res["layout"]["grid"], res["layout"]["tile"]) if mode == "grid" else f"panels 1x{world}")
+                    "(csrc/dist.hip)"}[mode]
+    par = "independent" if mode == "local" else "grid %dx%d nb=%d" % (*res["layout"]["grid"], res["layout"]["tile"])
     out = {
         "metric": ("IPM iterations/sec (Mehrotra predictor-corrector, condensed KKT + Cholesky), dense QP fp64"
                    if args.kkt_system == "condensed" else
@@ -657,7 +651,7 @@ def main():
         print(json.dumps(cpu_full_size(args, M, be)), flush=True)
         be.close()
         return
-    mode = {"local": "local", "distributed": "grid", "panels": "panels", None: "local" if world == 1 else "grid"}[args.kkt]
+    mode = {"local": "local", "distributed": "grid", None: "local" if world == 1 else "grid"}[args.kkt]
     if args.kkt_system != "condensed" and mode != "local":
         mode = "local"  # the augmented system is factorised on one GPU
     out = None

@@ -322,39 +322,35 @@ int32_t madqp_kkt_set_hdiag(madqp_kkt* kkt, const double* hdiag);
 typedef struct madqp_coo_map madqp_coo_map;
 int32_t madqp_coo_map_create(madqp_ctx* ctx, int64_t nnz, const int32_t* I_host, const int32_t* J_host,
                              int64_t nrows, int64_t ncols, int32_t symmetric, madqp_coo_map** out);
+/* The same for the pieces one rank (p, q) of a P x Q grid holds of a QP shared by all ranks (madqp_dkkt_create):
+ *   cols_cyclic   Jacobian entries whose column lies in a tile (width nb) of residue r mod R -> dst[i*ld + local
+ *                 column]; (R, r) = (P, p) gives A_I, (Q, q) gives A_J; all other entries are dropped;
+ *   tiles_cyclic  the lower tiles (I, J), I = p mod P, J = q mod Q, of a symmetric Hessian whose pattern is one
+ *                 triangle -> dst[local column * ld + local row] (the layout of the local K); diagonal tiles get both
+ *                 triangles.
+ * apply as above (target: nrows x local columns, resp. local columns x local rows). */
+int32_t madqp_coo_map_create_cols_cyclic(madqp_ctx* ctx, int64_t nnz, const int32_t* I_host, const int32_t* J_host,
+                                         int64_t nrows, int64_t ncols, int64_t nb, int32_t R, int32_t r,
+                                         madqp_coo_map** out);
+int32_t madqp_coo_map_create_tiles_cyclic(madqp_ctx* ctx, int64_t nnz, const int32_t* I_host, const int32_t* J_host,
+                                          int64_t n, int64_t nb, int32_t P, int32_t p, int32_t Q, int32_t q,
+                                          madqp_coo_map** out);
 int32_t madqp_coo_map_apply(madqp_coo_map* map, const double* vals, double* dst, int64_t ld);
 int32_t madqp_coo_map_destroy(madqp_coo_map* map);
 
-/* ----------------------------------------- multi-GPU factorisation pieces */
-/* One dense KKT over several GPUs, one process per GPU: block columns ("panels", starts and widths
- * multiples of 128, the last one may be short) are dealt round-robin to the ranks.  A rank assembles
- * and factors the panels it owns; a finished panel travels once to every other rank as a packed
- * image (the host broadcasts the buffer with RCCL), is unpacked into the local copy of L and applied
- * to the panels the receiver owns.  Afterwards every rank holds the whole factor, so
- * madqp_chol_solve / madqp_kkt_solve need no communication.  All calls are asynchronous on the
- * context's stream except factor_end.  Orchestration: madqp_jl_amd/dist.py. */
-/* madqp_syrk_assemble for the column ranges [ranges_host[2r], ranges_host[2r+1]) only (rows >= start) */
-int32_t madqp_syrk_assemble_cols(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B, int64_t ldb,
-                                 const double* w, const double* base, int64_t ldbase, const double* dvec,
-                                 double* C, int64_t ldc, int64_t nranges, const int64_t* ranges_host);
-/* build_kkt! (src/KKT/normalkkt.jl:166-180) restricted to those block columns of K */
-int32_t madqp_kkt_build_cols(madqp_kkt* kkt, const madqp_state* st, int64_t nranges, const int64_t* ranges_host);
+/* ----------------------------------------- factorisation pieces */
+/* One block column ("panel": start and width multiples of 128, the last one may be short) of a matrix the caller owns:
+ * the tile factorisation inside the P x Q distributed Cholesky below is built from these (csrc/dist.hip), and a host
+ * that schedules panels itself can use them the same way.  All calls are asynchronous on the context's stream. */
 /* the linear solver object of a KKT system and the order of its matrix (borrowed handle) */
 int32_t madqp_kkt_chol(madqp_kkt* kkt, madqp_chol** chol, int64_t* order);
 /* start a factorisation of the column-major lower matrix A (clears info) */
 int32_t madqp_chol_factor_begin(madqp_chol* s, double* A, int64_t lda);
 /* factor columns [j0, j0+w), which already carry the updates of all columns < j0 (all rows below too) */
 int32_t madqp_chol_factor_panel(madqp_chol* s, int64_t j0, int64_t w);
-/* A[c0:n, c0:c0+cw] -= L[c0:n, p0:p0+pw] L[c0:c0+cw, p0:p0+pw]'  (lower part; p0+pw <= c0) */
-int32_t madqp_chol_update_cols(madqp_chol* s, int64_t c0, int64_t cw, int64_t p0, int64_t pw);
-/* the same update for ncols panels of the caller, cols_host = (start, width) pairs ascending, one launch */
-int32_t madqp_chol_update_multi(madqp_chol* s, int64_t ncols, const int64_t* cols_host, int64_t p0, int64_t pw);
-/* packed image of a factored panel: [info, 0 | inverse diagonal blocks | L[j0:n, j0:j0+w]] */
-int32_t madqp_chol_panel_doubles(madqp_chol* s, int64_t j0, int64_t w, int64_t* count_host);
+/* packed image of a factored panel: [info, 0 | inverse diagonal blocks | L[j0:n, j0:j0+w]],
+ * 2 + ceil(w/128) * 2 * 128 * 128 + w * (n - j0) doubles */
 int32_t madqp_chol_panel_pack(madqp_chol* s, int64_t j0, int64_t w, double* buf);
-int32_t madqp_chol_panel_unpack(madqp_chol* s, int64_t j0, int64_t w, const double* buf);
-/* info as madqp_chol_factor (first failing column over all ranks: it travels in the packed image) */
-int32_t madqp_chol_factor_end(madqp_chol* s, int32_t* info_host);
 
 /* ----------------------------------------- one dense KKT matrix on a P x Q grid of GPUs */
 /* 2-D block-cyclic distributed Cholesky + triangular solves, one process per GPU: the AbstractLinearSolver contract

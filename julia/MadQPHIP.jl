@@ -10,6 +10,8 @@
 #   HIPCondensedKKTSystem / HIPAugmentedKKTSystem / HIPNormalKKTSystem  <: MadNLP.AbstractKKTSystem
 #       (modelled on NormalKKTSystem, src/KKT/normalkkt.jl; same generic fields, same methods)
 #   HIPCholeskySolver <: MadNLP.AbstractLinearSolver   (ctor `Solver(aug_com; opt)`, factorize!, solve!(s, rhs))
+#   HIPDistributedKKTSystem / HIPDistributedCholeskySolver: the condensed system of ONE QP on a P x Q grid of GPUs,
+#       one process per GPU (madqp_dist_* / madqp_dkkt_*, RCCL issued by the library)
 #   methods of MadIPM's per-variable kernels (src/kernels.jl) specialised on these KKT types, so that `mpc!`
 #   (src/solver.jl:254-345) runs unchanged with every vector on the device.
 #
@@ -296,6 +298,221 @@ function mul!(w::MadNLP.AbstractKKTVector{T}, kkt::HIPKKTSystem, v::MadNLP.Abstr
     return w
 end
 
+# --------------------------------------------------------------------------- one QP over a P x Q grid of GPUs
+# SURVEY.md 8e / BASELINE configs[4]: every rank runs the SAME MadIPM loop on replicated vectors (identical branches:
+# every scalar is computed from bitwise identical vectors); only this KKT system knows that K = H + Sigma_x + A' Theta A,
+# its Cholesky factor and the products with H and A are spread over the grid (madqp_dist_*, madqp_dkkt_* of
+# include/madqp.h; the collectives -- RCCL over xGMI -- are issued by the library).  One process per GPU; the 128 bytes
+# of RCCL's unique id travel from rank 0 over whatever the launcher offers (`share_id`, e.g. `id -> MPI.Bcast!(id, 0,
+# comm)`), once.
+#
+#   MadQPHIP.configure_distributed!(rank, world; P, Q, nb = 1024, share_id = id -> MPI.Bcast!(id, 0, comm))
+#   solver = MadIPM.MPCSolver(qp; kkt_system = MadQPHIP.HIPDistributedKKTSystem,
+#                             linear_solver = MadQPHIP.HIPDistributedCholeskySolver, ...)
+#
+# The model callbacks are evaluated on every rank as in a single-process run (the COO buffers `jac`, `hess` are
+# replicated: nnz values); compress_jacobian! / compress_hessian! keep only this rank's pieces -- the columns of A of its
+# tile rows (A_I) and of its tile columns (A_J), its lower tiles of H (madqp_coo_map_create_cols_cyclic /
+# _tiles_cyclic) -- so nothing of order n^2 or m n is replicated on the device.
+Base.@kwdef mutable struct DistributedConfig
+    rank::Int = 0
+    world::Int = 1
+    P::Int = 1
+    Q::Int = 1
+    nb::Int = 1024
+    share_id::Function = identity     # in-place broadcast of a Vector{UInt8}(128) from rank 0 to all ranks
+end
+const DIST_CONFIG = Ref(DistributedConfig())
+function configure_distributed!(rank, world; P, Q, nb = 1024, share_id = identity)
+    P * Q == world || error("P * Q must equal the number of ranks")
+    DIST_CONFIG[] = DistributedConfig(rank, world, P, Q, nb, share_id)
+end
+
+mutable struct HIPDistributedMatrix{T}      # aug_com of the distributed system: the grid + the KKT object on it
+    dist::Ptr{Cvoid}          # madqp_dist*
+    dkkt::Ptr{Cvoid}          # madqp_dkkt* (set once the operands exist)
+    ctx::Context
+    order::Int
+    maps::Vector{Ptr{Cvoid}}
+    function HIPDistributedMatrix{T}(dist, ctx, order) where {T}
+        A = new{T}(dist, C_NULL, ctx, order, Ptr{Cvoid}[])
+        finalizer(A) do a
+            a.dkkt != C_NULL && ccall((:madqp_dkkt_destroy, libmadqp), Int32, (Ptr{Cvoid},), a.dkkt)
+            ccall((:madqp_dist_destroy, libmadqp), Int32, (Ptr{Cvoid},), a.dist)
+            foreach(mp -> ccall((:madqp_coo_map_destroy, libmadqp), Int32, (Ptr{Cvoid},), mp), a.maps)
+        end
+        return A
+    end
+end
+
+mutable struct HIPDistributedCholeskySolver{T} <: MadNLP.AbstractLinearSolver{T}
+    aug_com::HIPDistributedMatrix{T}
+    info::Int32
+    opt::HIPCholeskyOptions
+    logger::MadNLP.MadNLPLogger
+end
+HIPDistributedCholeskySolver(aug_com::HIPDistributedMatrix{T}; opt = HIPCholeskyOptions(),
+                             logger = MadNLP.MadNLPLogger()) where {T} =
+    HIPDistributedCholeskySolver{T}(aug_com, Int32(0), opt, logger)
+MadNLP.default_options(::Type{HIPDistributedCholeskySolver}) = HIPCholeskyOptions()
+MadNLP.introduce(::HIPDistributedCholeskySolver) = "madqp-hip 2-D block-cyclic distributed fp64 Cholesky (MFMA + RCCL, gfx950)"
+MadNLP.is_supported(::Type{HIPDistributedCholeskySolver}, ::Type{Float64}) = true
+MadNLP.is_inertia(::HIPDistributedCholeskySolver) = true
+MadNLP.inertia(s::HIPDistributedCholeskySolver) = s.info == 0 ? (s.aug_com.order, 0, 0) : (Int(s.info) - 1, 0, 1)
+MadNLP.improve!(::HIPDistributedCholeskySolver) = false
+MadIPM.is_factorized(s::HIPDistributedCholeskySolver) = s.info == 0
+function MadNLP.factorize!(s::HIPDistributedCholeskySolver)    # info is identical on every rank (dist_core.inc)
+    info = Ref{Int32}(0)
+    check(s.aug_com.ctx, ccall((:madqp_dkkt_factorize, libmadqp), Int32, (Ptr{Cvoid}, Ref{Int32}), s.aug_com.dkkt, info))
+    s.info = info[]
+    return s
+end
+function MadNLP.solve!(s::HIPDistributedCholeskySolver, rhs::AbstractVector)   # replicated right-hand side, in place
+    check(s.aug_com.ctx, ccall((:madqp_dist_solve, libmadqp), Int32, (Ptr{Cvoid}, Ptr{Float64}), s.aug_com.dist, dptr(rhs)))
+    return rhs
+end
+
+struct HIPDistributedKKTSystem{T, VT, MT, QN, VI, LS} <: MadNLP.AbstractKKTSystem{T, VT, MT, QN}
+    aug_com::HIPDistributedMatrix{T}
+    ctx::Context
+    Hloc::MT; A_I::MT; A_J::MT          # this rank's pieces (device), layouts of madqp_dkkt_create
+    ld::Int; ncp::Int                   # leading dimension / padded column count of the local matrix
+    jac::VT; hess::VT                   # replicated callback buffers
+    jacI_map::Ptr{Cvoid}; jacJ_map::Ptr{Cvoid}; hess_map::Ptr{Cvoid}
+    reg::VT; pr_diag::VT; du_diag::VT
+    l_diag::VT; u_diag::VT; l_lower::VT; u_lower::VT
+    linear_solver::LS
+    ind_ineq::VI; ind_lb::VI; ind_ub::VI
+    ind_lb0::VI; ind_ub0::VI
+    cstate::Base.RefValue{CState}
+    n::Int; m::Int; nx::Int
+end
+
+function MadNLP.create_kkt_system(
+    ::Type{HIPDistributedKKTSystem}, cb::MadNLP.SparseCallback{T, VT}, ind_cons, linear_solver::Type;
+    opt_linear_solver = MadNLP.default_options(linear_solver),
+    hessian_approximation = MadNLP.ExactHessian, qn_options = MadNLP.QuasiNewtonOptions(),
+) where {T, VT}
+    cfg = DIST_CONFIG[]
+    nx, m = cb.nvar, cb.ncon
+    ind_ineq = ind_cons.ind_ineq
+    ns = length(ind_ineq); n = nx + ns
+    nlb, nub = length(ind_cons.ind_lb), length(ind_cons.ind_ub)
+    ctx = Context()
+    id = zeros(UInt8, 128)                       # RCCL's unique id: drawn on rank 0, shipped by the launcher's channel
+    if cfg.world > 1
+        cfg.rank == 0 && check(ctx, ccall((:madqp_dist_unique_id, libmadqp), Int32, (Ptr{Cvoid}, Ptr{UInt8}), ctx.ptr, id))
+        cfg.share_id(id)
+    end
+    dref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ctx, ccall((:madqp_dist_create, libmadqp), Int32,
+                     (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int64, Int64, Ptr{UInt8}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                     ctx.ptr, cfg.rank, cfg.world, cfg.P, cfg.Q, nx, cfg.nb, cfg.world > 1 ? pointer(id) : C_NULL, C_NULL, dref))
+    aug_com = HIPDistributedMatrix{T}(dref[], ctx, nx)
+    lay = zeros(Int64, 8)                        # (p, q, tile rows, tile columns, mloc, nloc, ld, ncp)
+    check(ctx, ccall((:madqp_dist_layout, libmadqp), Int32, (Ptr{Cvoid}, Ptr{Int64}), dref[], lay))
+    p, q, ld, ncp = Int(lay[1]), Int(lay[2]), Int(lay[7]), Int(lay[8])
+    m16 = max(cld(m, 16) * 16, 1)
+    zeros_dev(r, c) = reshape(fill!(VT(undef, r * c), zero(T)), r, c)
+    A_I, A_J = zeros_dev(ld, m16), zeros_dev(ncp, m16)     # Julia (ld x m16) = the library's m16 rows of length ld
+    Hloc = cb.nnzh > 0 ? zeros_dev(ld, ncp) : zeros_dev(0, 0)   # Julia (ld x ncp) = the local matrix, column-major
+    jI = MadNLP.create_array(cb, Int32, cb.nnzj); jJ = MadNLP.create_array(cb, Int32, cb.nnzj)
+    MadNLP._jac_sparsity_wrapper!(cb, jI, jJ)
+    hI = MadNLP.create_array(cb, Int32, cb.nnzh); hJ = MadNLP.create_array(cb, Int32, cb.nnzh)
+    cb.nnzh > 0 && MadNLP._hess_sparsity_wrapper!(cb, hI, hJ)
+    jIh, jJh = Vector{Int32}(Array(jI)), Vector{Int32}(Array(jJ))
+    function cols_map(R, r)
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ctx, ccall((:madqp_coo_map_create_cols_cyclic, libmadqp), Int32,
+                         (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Int64, Int64, Int64, Int32, Int32, Ref{Ptr{Cvoid}}),
+                         ctx.ptr, length(jIh), jIh, jJh, m, nx, cfg.nb, R, r, ref))
+        return ref[]
+    end
+    jacI_map, jacJ_map = cols_map(cfg.P, p), cols_map(cfg.Q, q)
+    hess_map = C_NULL
+    if cb.nnzh > 0
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        hIh, hJh = Vector{Int32}(Array(hI)), Vector{Int32}(Array(hJ))
+        check(ctx, ccall((:madqp_coo_map_create_tiles_cyclic, libmadqp), Int32,
+                         (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Int64, Int64, Int32, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+                         ctx.ptr, length(hIh), hIh, hJh, nx, cfg.nb, cfg.P, p, cfg.Q, q, ref))
+        hess_map = ref[]
+    end
+    append!(aug_com.maps, filter(!=(C_NULL), [jacI_map, jacJ_map, hess_map]))
+    kref = Ref{Ptr{Cvoid}}(C_NULL)
+    ineq0 = Int64.(Array(ind_ineq)) .- 1
+    check(ctx, ccall((:madqp_dkkt_create, libmadqp), Int32,
+                     (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64},
+                      Int64, Ref{Ptr{Cvoid}}),
+                     dref[], nx, m, ns, ineq0, cb.nnzh > 0 ? dptr(Hloc) : NULLF, ld, dptr(A_I), ld, dptr(A_J), ncp, kref))
+    aug_com.dkkt = kref[]
+    ls = linear_solver(aug_com; opt = opt_linear_solver)
+    mk(k) = VT(undef, k)
+    reg, pr_diag, du_diag = mk(n), mk(n), mk(m)
+    l_diag, u_diag, l_lower, u_lower = mk(nlb), mk(nub), mk(nlb), mk(nub)
+    ind_lb0, ind_ub0 = ind_cons.ind_lb .- 1, ind_cons.ind_ub .- 1
+    cs = CState(n, m, nlb, nub, dptr(ind_lb0), dptr(ind_ub0),
+                NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF, NULLF,
+                dptr(reg), dptr(pr_diag), dptr(du_diag), dptr(l_diag), dptr(l_lower), dptr(u_diag), dptr(u_lower))
+    VI = typeof(ind_cons.ind_lb)
+    return HIPDistributedKKTSystem{T, VT, typeof(A_I), MadNLP.ExactHessian{T, VT}, VI, typeof(ls)}(
+        aug_com, ctx, Hloc, A_I, A_J, ld, ncp, mk(cb.nnzj), mk(cb.nnzh), jacI_map, jacJ_map, hess_map,
+        reg, pr_diag, du_diag, l_diag, u_diag, l_lower, u_lower, ls,
+        ind_ineq, ind_cons.ind_lb, ind_cons.ind_ub, ind_lb0, ind_ub0, Ref(cs), n, m, nx)
+end
+
+MadNLP.num_variables(kkt::HIPDistributedKKTSystem) = kkt.n
+MadNLP.get_jacobian(kkt::HIPDistributedKKTSystem) = kkt.jac
+MadNLP.get_hessian(kkt::HIPDistributedKKTSystem) = kkt.hess
+MadNLP.is_inertia_correct(kkt::HIPDistributedKKTSystem, num_pos, num_zero, num_neg) =
+    (num_zero == 0) && (num_pos == kkt.aug_com.order)
+function MadNLP.initialize!(kkt::HIPDistributedKKTSystem{T}) where {T}     # src/KKT/normalkkt.jl:136-147
+    fill!(kkt.reg, one(T)); fill!(kkt.pr_diag, one(T)); fill!(kkt.du_diag, zero(T))
+    fill!(kkt.l_lower, zero(T)); fill!(kkt.u_lower, zero(T)); fill!(kkt.l_diag, one(T)); fill!(kkt.u_diag, one(T))
+    return
+end
+function MadNLP.compress_jacobian!(kkt::HIPDistributedKKTSystem)          # this rank's two column subsets of A
+    for (mp, dst, ld) in ((kkt.jacI_map, kkt.A_I, kkt.ld), (kkt.jacJ_map, kkt.A_J, kkt.ncp))
+        check(kkt.ctx, ccall((:madqp_coo_map_apply, libmadqp), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64),
+                             mp, dptr(kkt.jac), dptr(dst), ld))
+    end
+    return
+end
+function MadNLP.compress_hessian!(kkt::HIPDistributedKKTSystem)           # this rank's lower tiles of H
+    kkt.hess_map == C_NULL && return
+    check(kkt.ctx, ccall((:madqp_coo_map_apply, libmadqp), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64),
+                         kkt.hess_map, dptr(kkt.hess), dptr(kkt.Hloc), kkt.ld))
+    return
+end
+function MadNLP.jtprod!(y::AbstractVector, kkt::HIPDistributedKKTSystem, x::AbstractVector)
+    check(kkt.ctx, ccall((:madqp_dkkt_jtprod, libmadqp), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+                         kkt.aug_com.dkkt, dptr(y), dptr(x)))
+    return y
+end
+function MadNLP.build_kkt!(kkt::HIPDistributedKKTSystem)                  # no communication: K_loc = H_loc + A_I' (Theta A_J)
+    check(kkt.ctx, ccall((:madqp_dkkt_build, libmadqp), Int32, (Ptr{Cvoid}, Ref{CState}), kkt.aug_com.dkkt, kkt.cstate))
+    return
+end
+function MadNLP.solve!(kkt::HIPDistributedKKTSystem, w::MadNLP.AbstractKKTVector)
+    check(kkt.ctx, ccall((:madqp_dkkt_solve, libmadqp), Int32, (Ptr{Cvoid}, Ref{CState}, Ptr{Float64}),
+                         kkt.aug_com.dkkt, kkt.cstate, dptr(MadNLP.full(w))))
+    return w
+end
+function mul!(w::MadNLP.AbstractKKTVector{T}, kkt::HIPDistributedKKTSystem, v::MadNLP.AbstractKKTVector,
+              alpha = one(T), beta = zero(T)) where {T}
+    check(kkt.ctx, ccall((:madqp_dkkt_mul, libmadqp), Int32,
+                         (Ptr{Cvoid}, Ref{CState}, Ptr{Float64}, Ptr{Float64}, Float64, Float64),
+                         kkt.aug_com.dkkt, kkt.cstate, dptr(MadNLP.full(w)), dptr(MadNLP.full(v)), alpha, beta))
+    return w
+end
+# The per-variable kernels below (set_aug_diagonal_reg! ... get_fraction_to_boundary_step) act on replicated vectors:
+# the distributed system takes the plain (non-K2.5) forms of the library through the same overrides.
+function MadIPM.set_aug_diagonal_reg!(kkt::HIPDistributedKKTSystem{T}, solver::MadNLP.AbstractMadNLPSolver{T}) where {T}
+    check(kkt.ctx, ccall((:madqp_set_aug_diagonal_reg, libmadqp), Int32, (Ptr{Cvoid}, Ref{CState}, Float64, Float64),
+                         kkt.ctx.ptr, state(solver), solver.del_w, solver.del_c))
+    return
+end
+
 # --------------------------------------------------------------------------- src/kernels.jl on the device
 # full state view of one solver (iterates + the KKT's diagonals), built on first use
 const STATES = WeakKeyDict{Any, Base.RefValue{CState}}()
@@ -318,7 +535,7 @@ macro k(name, argtypes, args...)
                                       (Ptr{Cvoid}, Ref{CState}, $(argtypes.args...)),
                                       solver.kkt.ctx.ptr, state(solver), $(args...)))))
 end
-const HIPSolver = MadIPM.MPCSolver{T, VT, VI, K} where {T, VT, VI, K <: HIPKKTSystem}
+const HIPSolver = MadIPM.MPCSolver{T, VT, VI, K} where {T, VT, VI, K <: Union{HIPKKTSystem, HIPDistributedKKTSystem}}
 
 # kernels.jl:128-146, and :149-165 for the K2.5 form: the library dispatches on the KKT object
 function MadIPM.set_aug_diagonal_reg!(kkt::HIPKKTSystem{T}, solver::MadNLP.AbstractMadNLPSolver{T}) where {T}
@@ -328,8 +545,9 @@ function MadIPM.set_aug_diagonal_reg!(kkt::HIPKKTSystem{T}, solver::MadNLP.Abstr
 end
 MadIPM.set_initial_primal_rhs!(solver::HIPSolver) = @k madqp_set_initial_primal_rhs ()
 MadIPM.set_initial_dual_rhs!(solver::HIPSolver) = @k madqp_set_initial_dual_rhs ()
-MadIPM.set_predictive_rhs!(solver::MadNLP.AbstractMadNLPSolver, ::HIPKKTSystem) = @k madqp_set_predictive_rhs ()
-MadIPM.set_correction_rhs!(solver::MadNLP.AbstractMadNLPSolver, ::HIPKKTSystem, mu::Float64,
+const AnyHIPKKT = Union{HIPKKTSystem, HIPDistributedKKTSystem}
+MadIPM.set_predictive_rhs!(solver::MadNLP.AbstractMadNLPSolver, ::AnyHIPKKT) = @k madqp_set_predictive_rhs ()
+MadIPM.set_correction_rhs!(solver::MadNLP.AbstractMadNLPSolver, ::AnyHIPKKT, mu::Float64,
                            clb::AbstractVector{Float64}, cub::AbstractVector{Float64}, ilb, iub) =
     @k madqp_set_correction_rhs (Float64,) mu
 MadIPM.get_correction!(solver::HIPSolver, clb, cub) = @k madqp_get_correction ()

@@ -136,19 +136,14 @@ _SIGNATURES = {
     "madqp_kkt_create_sparse": [vp, i32, i64, i64, i64, pi64, vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(vp)],
     "madqp_kkt_set_hdiag": [vp, vp],
     "madqp_coo_map_create": [vp, i64, vp, vp, i64, i64, i32, C.POINTER(vp)],
+    "madqp_coo_map_create_cols_cyclic": [vp, i64, vp, vp, i64, i64, i64, i32, i32, C.POINTER(vp)],
+    "madqp_coo_map_create_tiles_cyclic": [vp, i64, vp, vp, i64, i64, i32, i32, i32, i32, C.POINTER(vp)],
     "madqp_coo_map_apply": [vp, vp, vp, i64],
     "madqp_coo_map_destroy": [vp],
-    "madqp_syrk_assemble_cols": [vp, i64, i64, vp, i64, vp, vp, i64, vp, vp, i64, i64, pi64],
-    "madqp_kkt_build_cols": [vp, pstate, i64, pi64],
     "madqp_kkt_chol": [vp, C.POINTER(vp), pi64],
     "madqp_chol_factor_begin": [vp, vp, i64],
     "madqp_chol_factor_panel": [vp, i64, i64],
-    "madqp_chol_update_cols": [vp, i64, i64, i64, i64],
-    "madqp_chol_update_multi": [vp, i64, pi64, i64, i64],
-    "madqp_chol_panel_doubles": [vp, i64, i64, pi64],
     "madqp_chol_panel_pack": [vp, i64, i64, vp],
-    "madqp_chol_panel_unpack": [vp, i64, i64, vp],
-    "madqp_chol_factor_end": [vp, pi32],
     "madqp_dist_unique_id": [vp, vp],
     "madqp_dist_create": [vp, i32, i32, i32, i32, i64, i64, vp, vp, C.POINTER(vp)],
     "madqp_dist_destroy": [vp],

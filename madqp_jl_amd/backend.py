@@ -346,49 +346,11 @@ class HipBackend:
         self._ck(self.lib.madqp_kkt_eval(h, C.byref(st.cstruct), ptr(q), ptr(rhs), c0, C.byref(obj)))
         return obj.value
 
-    # ---- multi-GPU factorisation pieces (include/madqp.h, orchestrated by dist.py) ----
-    def kkt_build_cols(self, h, st, ranges):
-        flat = [int(v) for r in ranges for v in r]
-        arr = (C.c_int64 * max(1, len(flat)))(*flat)
-        self._ck(self.lib.madqp_kkt_build_cols(h, C.byref(st.cstruct), len(flat) // 2, arr))
-
     def kkt_chol(self, h):
         """(linear solver handle, order of its matrix) of a KKT object."""
         ch, n = C.c_void_p(), C.c_int64()
         self._ck(self.lib.madqp_kkt_chol(h, C.byref(ch), C.byref(n)))
         return ch, n.value
-
-    def chol_factor_begin(self, ch, A_ptr: int, lda: int):
-        self._ck(self.lib.madqp_chol_factor_begin(ch, C.c_void_p(A_ptr), lda))
-
-    def chol_factor_panel(self, ch, j0, w):
-        self._ck(self.lib.madqp_chol_factor_panel(ch, j0, w))
-
-    def chol_update_cols(self, ch, c0, cw, p0, pw):
-        self._ck(self.lib.madqp_chol_update_cols(ch, c0, cw, p0, pw))
-
-    def chol_update_multi(self, ch, cols, p0, pw):
-        """``cols``: [(start, width)] ascending, all right of the source panel; one launch."""
-        flat = [int(v) for c in cols for v in c]
-        if flat:
-            arr = (C.c_int64 * len(flat))(*flat)
-            self._ck(self.lib.madqp_chol_update_multi(ch, len(flat) // 2, arr, p0, pw))
-
-    def chol_panel_doubles(self, ch, j0, w) -> int:
-        n = C.c_int64()
-        self._ck(self.lib.madqp_chol_panel_doubles(ch, j0, w, C.byref(n)))
-        return n.value
-
-    def chol_panel_pack(self, ch, j0, w, buf):
-        self._ck(self.lib.madqp_chol_panel_pack(ch, j0, w, ptr(buf)))
-
-    def chol_panel_unpack(self, ch, j0, w, buf):
-        self._ck(self.lib.madqp_chol_panel_unpack(ch, j0, w, ptr(buf)))
-
-    def chol_factor_end(self, ch) -> int:
-        info = C.c_int32()
-        self._ck(self.lib.madqp_chol_factor_end(ch, C.byref(info)))
-        return info.value
 
     # ---- native driver of one MPC iteration (csrc/mpc.hip) ----
     def mpc_create(self, kkt_h, st, w1, w2, q, rhs, c0, norm_b, norm_c, copt):

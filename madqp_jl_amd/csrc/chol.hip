@@ -1173,19 +1173,14 @@ int32_t madqp_chol_factor_batched(madqp_ctx* ctx, double* A, int64_t lda, int64_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pieces of the factorisation for the multi-GPU path (madqp_jl_amd/dist.py): block
-// columns ("panels", width a multiple of 128) are dealt round-robin to the ranks; a rank factors a
-// panel it owns once every panel to its left has been applied to it, packs it, the host broadcasts
-// the packed image (RCCL), the other ranks unpack it into their copy of L and apply it to the
-// panels they own.  All calls are asynchronous on the context's stream; only factor_end reads back.
+// Pieces of the factorisation for the multi-GPU path: the diagonal tile of a step of the 2-D block-cyclic
+// Cholesky (dist.hip: dop_potrf_tile) is an order-nb matrix the distributed object owns -- factor_begin adopts it,
+// factor_panel runs the blocked factorisation on it, panel_pack lays out [info | inverse diagonal blocks | L] for the
+// broadcast.  All asynchronous on the context's stream.
 namespace {
 __global__ void info_store_kernel(const int32_t* __restrict__ info, double* __restrict__ hdr) {
     hdr[0] = (double)*info;
     hdr[1] = 0.0;
-}
-__global__ void info_merge_kernel(int32_t* __restrict__ info, const double* __restrict__ hdr) {
-    const int32_t in = (int32_t)hdr[0];
-    if (in != 0) atomicCAS(info, 0, in);  // keep the first failing column, as on one GPU
 }
 constexpr int64_t PACK_HDR = 2;  // doubles: [info, 0] (keeps the payload 16-byte aligned)
 
@@ -1212,57 +1207,6 @@ extern "C" int32_t madqp_chol_factor_panel(madqp_chol* s, int64_t j0, int64_t w)
     return factor_range(s, s->A, s->lda, j0, w);
 }
 
-extern "C" int32_t madqp_chol_update_cols(madqp_chol* s, int64_t c0, int64_t cw, int64_t p0, int64_t pw) {
-    if (!s) return MADQP_ERR_ARG;
-    ARG_TRY(s->ctx, panel_ok(s, c0, cw) && panel_ok(s, p0, pw) && p0 + pw <= c0);
-    return panel_update(s->ctx, s->A, s->lda, s->n, c0, p0, cw, p0 + pw);
-}
-
-// The same update for several panels of the caller in ONE launch: cols_host = ncols pairs
-// (start, width), ascending; all of them right of the source panel [p0, p0+pw).
-extern "C" int32_t madqp_chol_update_multi(madqp_chol* s, int64_t ncols, const int64_t* cols_host, int64_t p0,
-                                           int64_t pw) {
-    if (!s) return MADQP_ERR_ARG;
-    madqp_ctx* ctx = s->ctx;
-    ARG_TRY(ctx, ncols >= 0 && (ncols == 0 || cols_host) && panel_ok(s, p0, pw));
-    if (ncols == 0) return MADQP_OK;
-    const int64_t n = s->n, lda = s->lda, cmin = cols_host[0];
-    std::vector<int64_t> rel((size_t)(2 * ncols));
-    for (int64_t r = 0; r < ncols; ++r) {
-        const int64_t c0 = cols_host[2 * r], cw = cols_host[2 * r + 1];
-        ARG_TRY(ctx, panel_ok(s, c0, cw) && p0 + pw <= c0 && (r == 0 || c0 >= cols_host[2 * r - 2] + cols_host[2 * r - 1]));
-        rel[(size_t)(2 * r)] = c0 - cmin;
-        rel[(size_t)(2 * r + 1)] = c0 + cw - cmin;
-    }
-    GemmArgs g{};
-    g.X = s->A + cmin + p0 * lda;
-    g.ldx = lda;
-    g.Y = g.X;
-    g.ldy = lda;
-    g.C = s->A + cmin + cmin * lda;
-    g.ldc = lda;
-    g.Cin = g.C;
-    g.ldcin = lda;
-    g.alpha = -1.0;
-    g.beta = 1.0;
-    g.M = n - cmin;
-    g.N = n - cmin;
-    g.K = pw;
-    const int64_t npad = (n + NB - 1) / NB * NB;
-    if (lda >= npad) g.Mread = g.Nread = npad - cmin;
-    g.diag_off = 0;
-    g.lower_only = 1;
-    return madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_GEMM, rel.data(), ncols);
-}
-
-extern "C" int32_t madqp_chol_panel_doubles(madqp_chol* s, int64_t j0, int64_t w, int64_t* count_host) {
-    if (!s || !count_host) return MADQP_ERR_ARG;
-    ARG_TRY(s->ctx, j0 >= 0 && w > 0 && j0 % NB == 0 && j0 + w <= s->n);
-    const int64_t nblk = (w + NB - 1) / NB;
-    *count_host = PACK_HDR + nblk * WBLK + w * (s->n - j0);
-    return MADQP_OK;
-}
-
 // buf = [info, 0 | inverse diagonal blocks of the panel | L[j0:n, j0+c] for c = 0..w-1]
 extern "C" int32_t madqp_chol_panel_pack(madqp_chol* s, int64_t j0, int64_t w, double* buf) {
     if (!s) return MADQP_ERR_ARG;
@@ -1277,34 +1221,6 @@ extern "C" int32_t madqp_chol_panel_pack(madqp_chol* s, int64_t j0, int64_t w, d
     HIP_TRY(ctx, hipMemcpy2DAsync(buf + PACK_HDR + nblk * WBLK, rows * sizeof(double),
                                   s->A + j0 + j0 * s->lda, s->lda * sizeof(double), rows * sizeof(double),
                                   (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
-    return MADQP_OK;
-}
-
-extern "C" int32_t madqp_chol_panel_unpack(madqp_chol* s, int64_t j0, int64_t w, const double* buf) {
-    if (!s) return MADQP_ERR_ARG;
-    madqp_ctx* ctx = s->ctx;
-    ARG_TRY(ctx, panel_ok(s, j0, w) && buf);
-    ProfScope ps(ctx, MADQP_PROF_VEC);
-    const int64_t nblk = (w + NB - 1) / NB, rows = s->n - j0;
-    hipLaunchKernelGGL(info_merge_kernel, dim3(1), dim3(1), 0, ctx->stream, s->d_info, buf);
-    LAUNCH_CHECK(ctx);
-    HIP_TRY(ctx, hipMemcpyAsync(s->winv + (j0 / NB) * WBLK, buf + PACK_HDR, nblk * WBLK * sizeof(double),
-                                hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpy2DAsync(s->A + j0 + j0 * s->lda, s->lda * sizeof(double),
-                                  buf + PACK_HDR + nblk * WBLK, rows * sizeof(double), rows * sizeof(double),
-                                  (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
-    return MADQP_OK;
-}
-
-extern "C" int32_t madqp_chol_factor_end(madqp_chol* s, int32_t* info_host) {
-    if (!s) return MADQP_ERR_ARG;
-    madqp_ctx* ctx = s->ctx;
-    ARG_TRY(ctx, s->A && info_host);
-    int32_t info = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&info, s->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *info_host = info;
-    s->factored = (info == 0);
     return MADQP_OK;
 }
 

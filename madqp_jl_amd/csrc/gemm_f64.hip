@@ -562,16 +562,6 @@ extern "C" int32_t madqp_syrk_assemble(madqp_ctx* ctx, int64_t n, int64_t kdim, 
     return syrk_assemble_impl(ctx, n, kdim, B, ldb, w, base, ldbase, dvec, C, ldc, 0, nullptr);
 }
 
-extern "C" int32_t madqp_syrk_assemble_cols(madqp_ctx* ctx, int64_t n, int64_t kdim, const double* B,
-                                            int64_t ldb, const double* w, const double* base,
-                                            int64_t ldbase, const double* dvec, double* C, int64_t ldc,
-                                            int64_t nranges, const int64_t* ranges_host) {
-    ARG_TRY(ctx, ctx != nullptr);
-    ARG_TRY(ctx, nranges >= 0 && (nranges == 0 || ranges_host));
-    if (nranges == 0) return MADQP_OK;
-    return syrk_assemble_impl(ctx, n, kdim, B, ldb, w, base, ldbase, dvec, C, ldc, nranges, ranges_host);
-}
-
 // ------------------------------------------------------------------ hardware probe
 namespace {
 __global__ __launch_bounds__(256) void mfma_f64_probe_kernel(int iters, double* sink) {

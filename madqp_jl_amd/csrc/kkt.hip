@@ -531,14 +531,6 @@ extern "C" int32_t madqp_kkt_build(madqp_kkt* k, const madqp_state* st) {
 // build_kkt! restricted to the block columns [ranges[2r], ranges[2r+1]) of the lower triangle
 // (multi-GPU path: a rank assembles the panels it owns).  Theta and the vectors the solves read
 // are computed in full, so solve!/mul! work on every rank.
-extern "C" int32_t madqp_kkt_build_cols(madqp_kkt* k, const madqp_state* st, int64_t nranges,
-                                        const int64_t* ranges_host) {
-    if (!k) return MADQP_ERR_ARG;
-    ARG_TRY(k->ctx, nranges >= 0 && (nranges == 0 || ranges_host));
-    static const int64_t none[2] = {0, 0};
-    return kkt_build_impl(k, st, nranges ? nranges : 1, nranges ? ranges_host : none);
-}
-
 extern "C" int32_t madqp_kkt_chol(madqp_kkt* k, madqp_chol** chol, int64_t* order) {
     if (!k || !chol) return MADQP_ERR_ARG;
     *chol = k->chol;

@@ -50,8 +50,6 @@ class IPMOptions:
         # MadNLP.MakeParameter ("make_parameter": fixed variables leave the problem, DeviceQP.eliminate_fixed) otherwise
         # -- here the normal equations.  None = that rule; "error" refuses fixed variables.
         fixed_variable_treatment=None,
-        distributed=False,  # True: assembly + Cholesky shared by the ranks of torch.distributed (dist.py)
-        panel_width=None,  # block-column width of the distributed factorisation (multiple of 128)
         driver="python",  # "python": this package drives each kernel; "native": one C call per iteration
         # extension (0 = the reference's solve_system!, src/linear_solver.jl:19-45): steps of iterative refinement with the
         # residual that solve_system! forms anyway.  The explicit 128 x 128 block inverses of the device factorisation

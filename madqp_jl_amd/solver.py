@@ -120,7 +120,7 @@ class MPCSolver:
         if diag_h and not isinstance(qp.A, DeviceCSR) and self.opt.kkt_system != "augmented":
             raise ValueError("a diagonal Hessian (1-D tensor) needs the sparse front end (A as DeviceCSR) "
                              "or kkt_system='augmented'")
-        if self.opt.kkt_system in ("augmented", "scaled_augmented") and self.opt.distributed:
+        if self.opt.kkt_system in ("augmented", "scaled_augmented") and hasattr(qp, "grid"):
             raise ValueError("the augmented KKT system is factorised on one GPU")
         if self.opt.kkt_system == "normal" and qp.H is not None and not diag_h:
             raise ValueError("The KKT system NormalKKTSystem supports only linear programs.")
@@ -146,8 +146,6 @@ class MPCSolver:
             raise ValueError(f"unknown driver {self.opt.driver!r}")
         if hasattr(qp, "grid") and self.opt.driver == "native":
             raise ValueError("the native driver factorizes on one GPU; a DistributedQP needs driver='python'")
-        if self.opt.distributed and self.opt.driver == "native":
-            raise ValueError("the native driver factorizes on one GPU; use driver='python' with distributed=True")
         self._native = None  # madqp_mpc handle (driver="native")
         self._info = CMpcInfo()
         self._fact_closed = 0  # factorizations of KKT objects that initialize() has already released
@@ -343,17 +341,7 @@ class MPCSolver:
             if opt.kkt_system != "condensed":
                 raise ValueError("the P x Q distributed path factorises the condensed KKT system")
             return HIPDistributedCondensedKKTSystem2D(be, st, nx, self.ind_ineq, self.qp.grid, self.H, self.A_I, self.A_J)
-        extra = {}
-        if opt.distributed:  # one KKT system over the ranks of the default process group
-            from . import dist as D
-
-            normal_cls, condensed_cls = D.HIPDistributedNormalKKTSystem, D.HIPDistributedCondensedKKTSystem
-            extra = dict(panel_width=opt.panel_width)
-        else:
-            normal_cls, condensed_cls = HIPNormalKKTSystem, HIPCondensedKKTSystem
         if isinstance(self.A, DeviceCSR):  # sparse front end: dense K / Cholesky, CSR products
-            if opt.distributed:
-                raise ValueError("the sparse front end runs on one GPU")
             cls = {"normal": HIPSparseNormalKKTSystem, "augmented": HIPSparseAugmentedKKTSystem,
                    "condensed": HIPSparseCondensedKKTSystem}[opt.kkt_system]
             return cls(be, st, nx, self.ind_ineq, self.H, self.A)
@@ -363,8 +351,8 @@ class MPCSolver:
             return HIPScaledAugmentedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)
         if opt.kkt_system == "normal":
             self.At = self.A.t().contiguous()  # (nx, m): the layout the normal-equations GEMM consumes
-            return normal_cls(be, st, nx, self.ind_ineq, self.H, self.At, **extra)
-        return condensed_cls(be, st, nx, self.ind_ineq, self.H, self.A, **extra)
+            return HIPNormalKKTSystem(be, st, nx, self.ind_ineq, self.H, self.At)
+        return HIPCondensedKKTSystem(be, st, nx, self.ind_ineq, self.H, self.A)
 
     def initialize(self):  # :127-182
         qp, opt, st, be = self.qp, self.opt, self.st, self.be

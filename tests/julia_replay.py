@@ -171,6 +171,139 @@ class ReplayKKTSystem:
         return w
 
 
+class ReplayDistributedCholeskySolver:
+    """HIPDistributedCholeskySolver of the glue: factorize! -> madqp_dkkt_factorize, solve!(s, rhs) -> madqp_dist_solve."""
+
+    def __init__(self, be, aug_com):
+        self.be, self.aug_com, self.info = be, aug_com, 0
+
+    def factorize(self):
+        info = C.c_int32()
+        ccall(self.be, "madqp_dkkt_factorize", self.aug_com["dkkt"], C.byref(info))
+        self.info = info.value
+        return self
+
+    def is_factorized(self):
+        return self.info == 0
+
+    def solve(self, rhs):
+        ccall(self.be, "madqp_dist_solve", self.aug_com["dist"], ptr(rhs))
+        return rhs
+
+
+class ReplayDistributedKKTSystem:
+    """HIPDistributedKKTSystem of the glue (create_kkt_system and every method), for ONE rank of a P x Q grid; with
+    world == 1 no RCCL id is drawn (`cfg.world > 1 && ...` in the glue)."""
+
+    def __init__(self, be, nx, m, ind_ineq, ind_lb, ind_ub, jac_I, jac_J, hess_I, hess_J, rank=0, world=1, P=1, Q=1,
+                 nb=128, comm_ops=None):
+        self.be, self.nx, self.m = be, int(nx), int(m)
+        dev, f64 = be.device, torch.float64
+        self.ns = len(ind_ineq)
+        self.n = self.nx + self.ns
+        z = lambda k: torch.zeros(max(int(k), 1), dtype=f64, device=dev)[: int(k)]
+        d = C.c_void_p()
+        ccall(be, "madqp_dist_create", be.ctx, rank, world, P, Q, self.nx, nb, None, comm_ops, C.byref(d))
+        lay = (C.c_int64 * 8)()
+        ccall(be, "madqp_dist_layout", d, lay)
+        p, q, _, _, self.mloc, self.nloc, self.ld, self.ncp = list(lay)
+        m16 = max((self.m + 15) // 16 * 16, 1)
+        self.A_I = torch.zeros((m16, self.ld), dtype=f64, device=dev)
+        self.A_J = torch.zeros((m16, self.ncp), dtype=f64, device=dev)
+        nnzj, nnzh = len(jac_I), len(hess_I)
+        self.Hloc = torch.zeros((self.ncp, self.ld), dtype=f64, device=dev) if nnzh else None
+        jI, jJ = np.ascontiguousarray(jac_I, dtype=np.int32), np.ascontiguousarray(jac_J, dtype=np.int32)
+        hI, hJ = np.ascontiguousarray(hess_I, dtype=np.int32), np.ascontiguousarray(hess_J, dtype=np.int32)
+        self._keep = (jI, jJ, hI, hJ)
+
+        def cols_map(R, r):
+            h = C.c_void_p()
+            ccall(be, "madqp_coo_map_create_cols_cyclic", be.ctx, nnzj, jI.ctypes.data_as(C.c_void_p),
+                  jJ.ctypes.data_as(C.c_void_p), self.m, self.nx, nb, R, r, C.byref(h))
+            return h
+
+        self.jacI_map, self.jacJ_map = cols_map(P, p), cols_map(Q, q)
+        self.hess_map = None
+        if nnzh:
+            h = C.c_void_p()
+            ccall(be, "madqp_coo_map_create_tiles_cyclic", be.ctx, nnzh, hI.ctypes.data_as(C.c_void_p),
+                  hJ.ctypes.data_as(C.c_void_p), self.nx, nb, P, p, Q, q, C.byref(h))
+            self.hess_map = h
+        self.jac, self.hess = z(nnzj), z(nnzh)
+        ineq0 = (C.c_int64 * max(self.ns, 1))(*[int(i) for i in ind_ineq])
+        k = C.c_void_p()
+        ccall(be, "madqp_dkkt_create", d, self.nx, self.m, self.ns, ineq0, ptr(self.Hloc), self.ld, ptr(self.A_I),
+              self.ld, ptr(self.A_J), self.ncp, C.byref(k))
+        self.aug_com = {"dist": d, "dkkt": k}
+        self.linear_solver = ReplayDistributedCholeskySolver(be, self.aug_com)
+        n, m = self.n, self.m
+        self.ind_lb0 = torch.as_tensor(ind_lb, dtype=torch.int64, device=dev).contiguous()
+        self.ind_ub0 = torch.as_tensor(ind_ub, dtype=torch.int64, device=dev).contiguous()
+        nlb, nub = self.ind_lb0.numel(), self.ind_ub0.numel()
+        self.reg, self.pr_diag, self.du_diag = z(n), z(n), z(m)
+        self.l_diag, self.u_diag, self.l_lower, self.u_lower = z(nlb), z(nub), z(nlb), z(nub)
+        cs = CState()
+        cs.n, cs.m, cs.nlb, cs.nub = n, m, nlb, nub
+        cs.ind_lb, cs.ind_ub = ptr(self.ind_lb0), ptr(self.ind_ub0)
+        for f in ("reg", "pr_diag", "du_diag", "l_diag", "l_lower", "u_diag", "u_lower"):
+            setattr(cs, f, ptr(getattr(self, f)))
+        self.cstate = cs
+        self.n_factorizations = 0
+
+    def close(self):
+        if self.aug_com is not None:
+            self.be.lib.madqp_dkkt_destroy(self.aug_com["dkkt"])
+            self.be.lib.madqp_dist_destroy(self.aug_com["dist"])
+            for h in (self.jacI_map, self.jacJ_map, self.hess_map):
+                if h is not None:
+                    self.be.lib.madqp_coo_map_destroy(h)
+            self.aug_com = None
+
+    def num_variables(self):
+        return self.n
+
+    def get_jacobian(self):
+        return self.jac
+
+    def get_hessian(self):
+        return self.hess
+
+    def initialize(self):  # fill! of the glue (torch stands in for Julia's broadcasts)
+        for t, v in ((self.reg, 1.0), (self.pr_diag, 1.0), (self.du_diag, 0.0), (self.l_lower, 0.0), (self.u_lower, 0.0),
+                     (self.l_diag, 1.0), (self.u_diag, 1.0)):
+            t.fill_(v)
+
+    def set_aug_diagonal_reg(self, del_w, del_c):
+        ccall(self.be, "madqp_set_aug_diagonal_reg", self.be.ctx, C.byref(self.solver_state.cstruct), del_w, del_c)
+
+    def compress_jacobian(self):
+        for mp, dst, ld in ((self.jacI_map, self.A_I, self.ld), (self.jacJ_map, self.A_J, self.ncp)):
+            ccall(self.be, "madqp_coo_map_apply", mp, ptr(self.jac), ptr(dst), ld)
+
+    def compress_hessian(self):
+        if self.hess_map is not None:
+            ccall(self.be, "madqp_coo_map_apply", self.hess_map, ptr(self.hess), ptr(self.Hloc), self.ld)
+
+    def jtprod(self, out, y):
+        ccall(self.be, "madqp_dkkt_jtprod", self.aug_com["dkkt"], ptr(out), ptr(y))
+
+    def build_kkt(self):
+        ccall(self.be, "madqp_dkkt_build", self.aug_com["dkkt"], C.byref(self.cstate))
+
+    def factorize_wrapper(self):
+        self.build_kkt()
+        self.linear_solver.factorize()
+        self.n_factorizations += 1
+
+    def solve(self, w):
+        ccall(self.be, "madqp_dkkt_solve", self.aug_com["dkkt"], C.byref(self.cstate), ptr(w))
+        return w
+
+    def mul(self, w, v, alpha=1.0, beta=0.0):
+        ccall(self.be, "madqp_dkkt_mul", self.aug_com["dkkt"], C.byref(self.cstate), ptr(w), ptr(v), alpha, beta)
+        return w
+
+
 class ReplayState(M.State):
     """MPCSolver's vectors, with the KKT diagonals ALIASED to the fields of the KKT object (in Julia the solver
     reads ``solver.kkt.reg`` etc. -- there is one copy, owned by the KKT system)."""
@@ -301,10 +434,11 @@ class ReplayMPCSolver(M.MPCSolver):
     """MadIPM.MPCSolver with ``kkt_system = MadQPHIP.HIP*KKTSystem, linear_solver = MadQPHIP.HIPCholeskySolver``:
     the loop of solver.py, the plugin objects of this module, the model behind a SparseCallback-like COO interface."""
 
-    def __init__(self, qp, be, seed=0, **opts):
+    def __init__(self, qp, be, seed=0, distributed_tile=None, **opts):
         opts["driver"] = "python"
         super().__init__(qp, be, **opts)
         self._rng = np.random.default_rng(seed)
+        self._dist_nb = distributed_tile  # not None: kkt_system = MadQPHIP.HIPDistributedKKTSystem (one rank, tile nb)
 
     def _create_kkt_system(self):
         A = self.A.detach().cpu().numpy()
@@ -315,8 +449,12 @@ class ReplayMPCSolver(M.MPCSolver):
         else:
             hI, hJ, hv = np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0)
         st = self.st
-        kkt = ReplayKKTSystem(self.be, self.opt.kkt_system, self.nx, self.m, self.ind_ineq,
-                              st.ind_lb.cpu().numpy(), st.ind_ub.cpu().numpy(), self._jI, self._jJ, hI, hJ)
+        if self._dist_nb:
+            kkt = ReplayDistributedKKTSystem(self.be, self.nx, self.m, self.ind_ineq, st.ind_lb.cpu().numpy(),
+                                             st.ind_ub.cpu().numpy(), self._jI, self._jJ, hI, hJ, nb=self._dist_nb)
+        else:
+            kkt = ReplayKKTSystem(self.be, self.opt.kkt_system, self.nx, self.m, self.ind_ineq,
+                                  st.ind_lb.cpu().numpy(), st.ind_ub.cpu().numpy(), self._jI, self._jJ, hI, hJ)
         st.adopt(kkt)
         # eval_jac_wrapper! / eval_lag_hess_wrapper! (src/solver.jl:167,170): the callback fills the buffers, then
         # compress_*! moves them into the dense operands (QP: constant, evaluated once)

@@ -45,32 +45,6 @@ def test_setup_collectives_follow_the_group_backend():
         reduce_where("nccl", False)  # what round 2 did: a CPU tensor on an nccl-only group
 
 
-@pytest.mark.parametrize("world,n,nb,port", [(2, 700, 128, 29519), (3, 1000, 256, 29521), (2, 400, 512, 29523)])
-def test_distributed_cholesky_orchestration(tmp_path, world, n, nb, port):
-    """SURVEY.md 8e, one dense KKT over N ranks: the panel-cyclic right-looking driver (dist.py) over
-    gloo with numpy stand-ins for the rank-local kernels gives the Cholesky factor on every rank, ships
-    every panel exactly once, and agrees on LAPACK's info when the matrix is not positive definite."""
-    out = str(tmp_path / "rec")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "dist_chol_worker.py"), out, str(n), str(nb)]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stderr[-3000:]
-    recs = [json.load(open(f"{out}.{r}")) for r in range(world)]
-    npan = (n + nb - 1) // nb
-    for r, rec in enumerate(recs):
-        assert rec["spd_info"] == 0 and not rec["nan"] and rec["err"] < 1e-12
-        assert rec["factored"] == [p * nb for p in range(npan) if p % world == r]  # own panels, in order
-        # each owned panel q receives exactly one update from every panel to its left
-        assert rec["updates"] == sum(q for q in range(npan) if q % world == r)
-        assert rec["not_pd_info"] == 301  # first failing column (1-based), identical on all ranks (also when
-        # the whole matrix is one panel and rank 1 owns nothing)
-        assert rec["default_nb"] == [1024, 256, 256]
-    total = sum(rec["bytes_sent"] for rec in recs)
-    assert total == 8 * sum(2 + min(nb, n - j) * (n - j) for j in range(0, n, nb))  # each panel sent once
-
-
 def test_single_process_helpers():
     sys.path.insert(0, ROOT)
     import bench

@@ -215,18 +215,18 @@ def test_augmented_full_size_n5k_with_equalities(hip):
 
 
 def test_augmented_refuses_the_panel_pieces(hip):
-    """The multi-GPU panel pieces factor positive definite matrices only: on a quasi-definite object they return a
-    usage error (never a wrong factor), and the distributed solver refuses the augmented system up front."""
+    """The panel pieces (the tile factorisation of the distributed Cholesky, csrc/dist.hip) factor positive definite
+    matrices only: on a quasi-definite object they return a usage error, never a wrong factor."""
+    import ctypes as C
+
     ch = hip.chol_create(256)
     hip.chol_set_signature(ch, 128)
     A = torch.zeros((256, 256), dtype=torch.float64, device=hip.device)
     with pytest.raises(Exception):
-        hip.chol_factor_begin(ch, A.data_ptr(), 256)
+        hip._ck(hip.lib.madqp_chol_factor_begin(ch, C.c_void_p(A.data_ptr()), 256))
     with pytest.raises(Exception):
         hip.chol_set_signature(ch, 100)  # not a block boundary
     hip.chol_destroy(ch)
-    with pytest.raises(ValueError):
-        M.MPCSolver(to_device(Q.hs21(), hip), hip, kkt_system="augmented", distributed=True)
 
 
 K2_GOLDEN = {

@@ -98,6 +98,35 @@ def test_linear_solver_contract(rbe):
     kkt.close()
 
 
+def test_distributed_linear_solver_contract(rbe):
+    """HIPDistributedCholeskySolver: factorize! (madqp_dkkt_factorize, re-reads the matrix object) and solve!(s, rhs) in
+    place on the replicated right-hand side (madqp_dist_solve), as src/KKT/normalkkt.jl:99-101,196 use a linear solver."""
+    rng = np.random.default_rng(12)
+    qp = Q.synthetic_qp(4, 300, 60)
+    n = 300 + 60
+    jI, jJ, jv = JR.coo_pattern(qp.A, rng)
+    hI, hJ, hv = JR.coo_pattern(np.tril(qp.H), rng)
+    kkt = JR.ReplayDistributedKKTSystem(rbe, 300, 60, np.arange(60), np.arange(n), np.arange(n), jI, jJ, hI, hJ, nb=128)
+    kkt.get_jacobian().copy_(torch.as_tensor(jv, device=rbe.device))
+    kkt.compress_jacobian()
+    kkt.get_hessian().copy_(torch.as_tensor(hv, device=rbe.device))
+    kkt.compress_hessian()
+    kkt.initialize()
+    sig = rng.uniform(0.5, 2.0, n)
+    kkt.pr_diag.copy_(torch.as_tensor(sig, device=rbe.device))
+    kkt.du_diag.fill_(-1e-8)
+    kkt.factorize_wrapper()
+    assert kkt.linear_solver.is_factorized()
+    theta = sig[300:] / (1.0 + 1e-8 * sig[300:])
+    K = qp.H + np.diag(sig[:300]) + (qp.A.T * theta) @ qp.A
+    b = rng.standard_normal(300)
+    x = torch.as_tensor(b, device=rbe.device).clone()
+    assert kkt.linear_solver.solve(x) is x
+    ref = sla.cho_solve(sla.cho_factor(K, lower=True), b)
+    assert np.max(np.abs(x.cpu().numpy() - ref)) <= 1e-11 * np.max(np.abs(ref))
+    kkt.close()
+
+
 CASES = [
     ("simple_lp/normal", lambda: Q.simple_lp(), "normal", "normal", (1e-8, 0.0), 0),
     ("simple_lp/augmented", lambda: Q.simple_lp(), "augmented", "K2", (1e-8, 0.0), 0),
@@ -134,6 +163,79 @@ def test_madipm_loop_through_the_glue(rbe, name, make, form, oform, reg, ncorr):
     assert np.max(np.abs(r["multipliers"] - ref["multipliers"])) <= 1e-6
 
 
+@pytest.mark.parametrize("P,Q,nb,n", [(1, 1, 128, 300), (2, 3, 128, 1000), (2, 4, 256, 1900), (3, 2, 128, 130)])
+def test_cyclic_coo_maps_match_numpy(rbe, P, Q, nb, n):
+    """compress_jacobian! / compress_hessian! of HIPDistributedKKTSystem: for EVERY rank (p, q) of the grid, the
+    block-cyclic maps move the replicated COO callback values into exactly the pieces DistributedQP.from_dense cuts out
+    of the dense matrices (A_I, A_J, the lower tiles of H with complete diagonal tiles), bit for bit."""
+    import types
+
+    from madqp_jl_amd.dist2d import DistributedQP
+
+    rng = np.random.default_rng(P * 100 + Q)
+    m = 70
+    A = rng.standard_normal((m, n)) * (rng.random((m, n)) < 0.2)
+    G = rng.standard_normal((n, n)) * (rng.random((n, n)) < 0.05)
+    H = G + G.T + np.diag(rng.uniform(1, 2, n))
+    jI, jJ, jv = JR.coo_pattern(A, rng, duplicates=7)
+    hI, hJ, hv = JR.coo_pattern(np.tril(H), rng, duplicates=7)
+    T = (n + nb - 1) // nb
+    pad = lambda v: max(128, (v + 127) // 128 * 128)
+    dev = rbe.device
+    jv_d, hv_d = torch.as_tensor(jv, device=dev), torch.as_tensor(hv, device=dev)
+    cv = lambda a: a.ctypes.data_as(JR.C.c_void_p)
+    for p in range(P):
+        for q in range(Q):
+            mloc = sum(min(nb, n - I * nb) for I in range(p, T, P))
+            nloc = sum(min(nb, n - J * nb) for J in range(q, T, Q))
+            grid = types.SimpleNamespace(n=n, nb=nb, P=P, Q=Q, p=p, q=q, mloc=mloc, nloc=nloc, ld=pad(mloc), ncp=pad(nloc))
+            ref = DistributedQP.from_dense(types.SimpleNamespace(device=dev), grid, H, np.zeros(n), A, np.zeros(n),
+                                           np.ones(n), np.zeros(m), np.ones(m), np.zeros(n))
+            for R, r, want, ldw in ((P, p, ref.A_I, grid.ld), (Q, q, ref.A_J, grid.ncp)):
+                h = JR.C.c_void_p()
+                JR.ccall(rbe, "madqp_coo_map_create_cols_cyclic", rbe.ctx, len(jI), cv(jI), cv(jJ), m, n, nb, R, r, JR.C.byref(h))
+                got = torch.full_like(want, 0.0)
+                JR.ccall(rbe, "madqp_coo_map_apply", h, JR.ptr(jv_d), JR.ptr(got), ldw)
+                assert torch.allclose(got[:m], want[:m], rtol=0, atol=1e-15), (p, q, R)
+                rbe.lib.madqp_coo_map_destroy(h)
+            h = JR.C.c_void_p()
+            JR.ccall(rbe, "madqp_coo_map_create_tiles_cyclic", rbe.ctx, len(hI), cv(hI), cv(hJ), n, nb, P, p, Q, q, JR.C.byref(h))
+            got = torch.zeros_like(ref.H)
+            JR.ccall(rbe, "madqp_coo_map_apply", h, JR.ptr(hv_d), JR.ptr(got), grid.ld)
+            gi = (torch.arange(mloc) // nb * P + p)  # tile row of every local row
+            gj = (torch.arange(nloc) // nb * Q + q)
+            lower = (gi[None, :] >= gj[:, None]).to(dev)  # [local column, local row]: tiles on or below the diagonal
+            want = ref.H[:nloc, :mloc] * lower
+            assert torch.allclose(got[:nloc, :mloc], want, rtol=0, atol=1e-15), (p, q)
+            rbe.lib.madqp_coo_map_destroy(h)
+
+
+@pytest.mark.parametrize("name,make,ncorr,nb", [
+    ("synthetic_300_120", lambda: Q.synthetic_qp(20250614, 300, 120), 0, 128),
+    ("synthetic_300_120/gondzio", lambda: Q.synthetic_qp(77, 300, 120), 3, 256),
+    ("random_130_70_lp", lambda: Q.synthetic_qp(20250615, 130, 50, "lp"), 0, 128),
+])
+def test_madipm_loop_through_the_distributed_glue(rbe, name, make, ncorr, nb):
+    """MadIPM.solve!(MPCSolver(qp; kkt_system = MadQPHIP.HIPDistributedKKTSystem, linear_solver =
+    MadQPHIP.HIPDistributedCholeskySolver)) on one rank of a 1 x 1 grid: create_kkt_system (grid, block-cyclic COO maps,
+    madqp_dkkt_create), compress_*!, build_kkt!, factorize!, solve!, mul!, jtprod! -- against the oracle."""
+    qp = make()
+    reg = (1e-8, -1e-8)
+    s = JR.ReplayMPCSolver(to_device(qp, rbe), rbe, kkt_system="condensed", regularization=M.FixedRegularization(*reg),
+                           max_ncorr=ncorr, distributed_tile=nb)
+    r = s.solve()
+    assert type(s.kkt).__name__ == "ReplayDistributedKKTSystem"
+    s.close()
+    ref = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(*reg), max_ncorr=ncorr)
+    ref2 = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(*reg), max_ncorr=ncorr, refine_steps=1)
+    from parity import compare_traces_measured
+
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
+    compare_traces_measured(r["trace"], ref["trace"], ref2["trace"], name)
+    assert abs(r["objective"] - ref["objective"]) <= 1e-9 * max(1.0, abs(ref["objective"]))
+    assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+
+
 def test_every_symbol_the_glue_binds_was_replayed(rbe):
     """The ccall targets of julia/MadQPHIP.jl == the ABI symbols the replay touched (after one solve per form with
     Gondzio corrections, so that set_extra_correction! runs)."""
@@ -145,11 +247,16 @@ def test_every_symbol_the_glue_binds_was_replayed(rbe):
                                regularization=M.FixedRegularization(*reg), max_ncorr=2)
         assert s.solve()["status"] == M.SOLVE_SUCCEEDED
         s.close()
+    s = JR.ReplayMPCSolver(to_device(Q.dummy_qp(10, 5), rbe), rbe, kkt_system="condensed",
+                           regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=2, distributed_tile=128)
+    assert s.solve()["status"] == M.SOLVE_SUCCEEDED  # HIPDistributedKKTSystem on one rank
+    s.close()
     src = open(os.path.join(ROOT, "julia", "MadQPHIP.jl")).read()
     code = "\n".join(line.split("#", 1)[0] for line in src.splitlines())  # comments name optional bindings
     bound = set(re.findall(r"(?::|@k )(madqp_[a-z0-9_]+)", code))
     lifecycle = {"madqp_ctx_create", "madqp_ctx_destroy", "madqp_last_error", "madqp_kkt_destroy",
-                 "madqp_coo_map_destroy"}  # reached through HipBackend / close() here
+                 "madqp_coo_map_destroy", "madqp_dkkt_destroy", "madqp_dist_destroy",  # HipBackend / close() here
+                 "madqp_dist_unique_id"}  # several ranks only (`cfg.world > 1`): tests/test_gpu_dist2d.py drives it
     assert bound - lifecycle == JR.GLUE_ENTRY_POINTS - lifecycle, (
         sorted(bound - lifecycle - JR.GLUE_ENTRY_POINTS), sorted(JR.GLUE_ENTRY_POINTS - lifecycle - bound))
     assert bound <= set(M.EXPORTED_SYMBOLS)

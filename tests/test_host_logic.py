@@ -241,15 +241,13 @@ def test_augmented_kkt_driver_matches_oracle(make):
 
 def test_augmented_kkt_options():
     """Fixed variables default to RelaxBound for the augmented system (a condensed KKT type in the sense of
-    src/utils.jl:81); the inertia reported is the K2 one; the distributed factorisation refuses it."""
+    src/utils.jl:81); the inertia reported is the K2 one."""
     qp = Q.dummy_qp(20, 15, equality_cons=(0, 1), fixed_variables=(0, 1))
     s, r = run(qp, kkt_system="augmented", regularization=M.FixedRegularization(1e-8, 0.0))
     ref = mpc.solve(qp, kkt_system="K2", fixed_variable_treatment="relax_bound")
     assert r["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
     assert s.kkt.is_inertia_correct(*s.kkt.linear_solver.inertia())
     assert s.kkt.linear_solver.inertia() == (20, 0, 15) and "L diag" in s.kkt.linear_solver.introduce()
-    with pytest.raises(ValueError):
-        run(qp, kkt_system="augmented", distributed=True)
     with pytest.raises(ValueError):
         run(qp, kkt_system="no-such-system")
 
