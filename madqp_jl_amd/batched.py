@@ -27,7 +27,7 @@ class BatchedMPCSolver:
             raise ValueError("empty batch")
         self.be, self.qps = backend, list(qps)
         self.opt = IPMOptions(**opts)
-        if self.opt.kkt_system not in ("condensed", "normal") or self.opt.distributed or self.opt.check_residual:
+        if self.opt.kkt_system not in ("condensed", "normal") or self.opt.check_residual:
             raise ValueError("the batched driver supports the condensed KKT system and the normal equations, on one GPU")
         self.normal = self.opt.kkt_system == "normal"
         q0 = self.qps[0]

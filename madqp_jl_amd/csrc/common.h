@@ -152,6 +152,11 @@ int32_t madqp_gemv_impl(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t col
                         const double* A, int64_t lda, const double* x, double beta, double* y,
                         int prof_cls);
 
+// y(n) = alpha H x + beta y for a symmetric H (row r at H + r*ldh) from its LOWER triangle only: half the bytes of the
+// general product (gemv.hip)
+int32_t madqp_symv_lower(madqp_ctx* ctx, int64_t n, double alpha, const double* H, int64_t ldh, const double* x,
+                         double beta, double* y, int prof_cls);
+
 // sparse.hip
 int32_t madqp_spmv_csr(madqp_ctx* ctx, int64_t rows, const int64_t* rowptr, const int64_t* col, const double* val,
                        double alpha, const double* x, double beta, double* y, int prof_cls);

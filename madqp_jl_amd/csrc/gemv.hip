@@ -11,6 +11,7 @@
 //                                                              partials are combined by a second
 //                                                              kernel in a fixed order (deterministic)
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -142,7 +143,117 @@ __global__ __launch_bounds__(256) void scale_kernel(int64_t n, double beta, doub
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = (beta == 0.0) ? 0.0 : beta * y[i];
 }
+// ---- y = alpha H x + beta y for a SYMMETRIC H from its lower triangle only ------------------------------------
+// The Hessian products of the path (mul! with H for a QP, src/KKT/normalkkt.jl:207-219 + the H term; the model
+// evaluation H x + q, scripts/qp_gpu.jl:29-40) streamed the full matrix: 20 GB at n_x = 50 000, 3.3 ms, four to six
+// times per iteration.  Half of that is the same numbers again.  Here a workgroup owns a tile of SY_TR rows x SY_TC
+// columns on or below the diagonal, reads it once, and produces BOTH of its contributions:
+//   row part   p_r = sum_{c in tile, c <= r} H[r,c] x[c]   -> y[r]     (lane-local over 4 column groups, one wave sum per row)
+//   col part   q_c = sum_{r in tile, r >  c} H[r,c] x[r]   -> y[c]     (per lane, the 4 waves combined through LDS)
+// into partial[column tile][r] / partial2[row tile][c]; symv_reduce_kernel adds them in tile order: deterministic,
+// no atomics, 8 n^2/2 bytes + 0.2 GB of partials.
+constexpr int SY_TR = 256, SY_TC = 512;
+__global__ __launch_bounds__(256) void symv_lower_kernel(int64_t n, const double* __restrict__ H, int64_t ldh,
+                                                         const double* __restrict__ x, double* __restrict__ rowpart,
+                                                         double* __restrict__ colpart) {
+    __shared__ double red[4][SY_TC];
+    const int64_t ct = blockIdx.x, rt = blockIdx.y;
+    const int64_t r0 = rt * SY_TR, c0 = ct * SY_TC;
+    if (r0 + SY_TR - 1 < c0) return;  // wholly above the diagonal
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool interior = (r0 >= c0 + SY_TC) && (r0 + SY_TR <= n) && (c0 + SY_TC <= n);  // strictly below: no masks
+    double xc[4][2], a[4][2];
+    int64_t cc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        cc[g] = c0 + g * 128 + 2 * lane;
+        xc[g][0] = (cc[g] < n) ? x[cc[g]] : 0.0;
+        xc[g][1] = (cc[g] + 1 < n) ? x[cc[g] + 1] : 0.0;
+        a[g][0] = a[g][1] = 0.0;
+    }
+    const int64_t rend = (r0 + SY_TR < n) ? r0 + SY_TR : n;
+    for (int64_t r = r0 + w; r < rend; r += 4) {
+        const double xr = x[r];
+        const double* row = H + r * ldh;
+        double t = 0.0;
+        if (interior) {
+            double2_t v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const double2_t*>(row + cc[g]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                a[g][0] = fma(v[g].x, xr, a[g][0]);
+                a[g][1] = fma(v[g].y, xr, a[g][1]);
+                t = fma(v[g].x, xc[g][0], t);
+                t = fma(v[g].y, xc[g][1], t);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t c = cc[g];
+                const double h0 = (c <= r) ? row[c] : 0.0;          // c <= r < n: inside the row
+                const double h1 = (c + 1 <= r) ? row[c + 1] : 0.0;
+                if (c < r) a[g][0] = fma(h0, xr, a[g][0]);           // strictly lower: the mirrored entry's product
+                if (c + 1 < r) a[g][1] = fma(h1, xr, a[g][1]);
+                t = fma(h0, xc[g][0], t);
+                t = fma(h1, xc[g][1], t);
+            }
+        }
+        t = wave_sum(t);
+        if (lane == 0) rowpart[ct * n + r] = t;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        red[w][g * 128 + 2 * lane] = a[g][0];
+        red[w][g * 128 + 2 * lane + 1] = a[g][1];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SY_TC; i += 256) {
+        const int64_t c = c0 + i;
+        if (c < n) colpart[rt * n + c] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
+}
+// y_i = alpha (sum over the column tiles left of or on i's diagonal tile + sum over the row tiles from i's down) + beta y_i
+__global__ __launch_bounds__(256) void symv_reduce_kernel(int64_t n, double alpha, const double* __restrict__ rowpart,
+                                                          const double* __restrict__ colpart, double beta,
+                                                          double* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t rt_i = i / SY_TR, ct_i = i / SY_TC, nrt = (n + SY_TR - 1) / SY_TR;
+    const int64_t ct_last = (rt_i * SY_TR + SY_TR - 1) / SY_TC;  // column tiles that row tile rt_i has a workgroup for
+    double s = 0.0;
+    for (int64_t ct = 0; ct <= ct_last; ++ct) s += rowpart[ct * n + i];
+    for (int64_t rt = 2 * ct_i; rt < nrt; ++rt) s += colpart[rt * n + i];  // rt*256 + 255 >= ct_i*512  <=>  rt >= 2 ct_i
+    y[i] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[i];
+}
+static_assert(SY_TC == 2 * SY_TR, "symv_reduce_kernel's first row tile of a column tile");
+
 }  // namespace
+
+// y(n) = alpha H x + beta y with H symmetric, n x n, row (= column) r at H + r*ldh: the lower triangle is read.
+// Small or unaligned operands go through the general product (both triangles).
+int32_t madqp_symv_lower(madqp_ctx* ctx, int64_t n, double alpha, const double* H, int64_t ldh, const double* x,
+                         double beta, double* y, int prof_cls) {
+    ARG_TRY(ctx, ctx != nullptr && n >= 0);
+    if (n == 0) return MADQP_OK;
+    ARG_TRY(ctx, H && x && y && ldh >= n);
+    static const int64_t nmin = getenv("MADQP_SYMV_MIN") ? atoll(getenv("MADQP_SYMV_MIN")) : 4096;
+    const bool vec = (((uintptr_t)H) & 15) == 0 && (ldh % 2 == 0);
+    if (n < nmin || !vec) return madqp_gemv_impl(ctx, 0, n, n, alpha, H, ldh, x, beta, y, prof_cls);
+    const int64_t nrt = (n + SY_TR - 1) / SY_TR, nct = (n + SY_TC - 1) / SY_TC;
+    int32_t r = madqp_work_reserve(ctx, (size_t)(nrt + nct) * n * sizeof(double));
+    if (r) return r;
+    double* rowpart = ctx->d_work;
+    double* colpart = rowpart + nct * n;
+    ProfScope ps(ctx, prof_cls);
+    hipLaunchKernelGGL(symv_lower_kernel, dim3((unsigned)nct, (unsigned)nrt), dim3(256), 0, ctx->stream, n, H, ldh, x,
+                       rowpart, colpart);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, alpha, rowpart,
+                       colpart, beta, y);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
 
 int32_t madqp_gemv_impl(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t cols, double alpha,
                         const double* A, int64_t lda, const double* x, double beta, double* y,

@@ -662,8 +662,8 @@ static int32_t kkt_mul_impl(madqp_kkt* k, const madqp_state* st, double* w, cons
     k->u_is_A_of = nullptr;
     // wx = alpha A_full' vy + beta wx  (+ alpha H vx)
     if ((r = apply_At(k, alpha, v + n, beta, w))) return r;
-    if (k->H && nx)
-        if ((r = madqp_gemv_impl(ctx, 0, nx, nx, alpha, k->H, k->ldh, v, 1.0, w, MADQP_PROF_GEMV)))
+    if (k->H && nx)  // H is symmetric: its lower triangle is enough (gemv.hip: madqp_symv_lower)
+        if ((r = madqp_symv_lower(ctx, nx, alpha, k->H, k->ldh, v, 1.0, w, MADQP_PROF_GEMV)))
             return r;
     if (k->hdiag && nx) {
         ProfScope ps(ctx, MADQP_PROF_VEC);
@@ -697,7 +697,7 @@ int32_t madqp_q_kkt_eval(madqp_kkt* k, const madqp_state* st, const double* q, c
     ARG_TRY(ctx, (k->nx == 0 || q) && (k->m == 0 || rhs));
     const int64_t nx = k->nx, n = st->n;
     if (k->H && nx)
-        if ((r = madqp_gemv_impl(ctx, 0, nx, nx, 1.0, k->H, k->ldh, st->x, 0.0, st->f, MADQP_PROF_GEMV)))
+        if ((r = madqp_symv_lower(ctx, nx, 1.0, k->H, k->ldh, st->x, 0.0, st->f, MADQP_PROF_GEMV)))
             return r;
     if (k->hdiag && nx) {
         ProfScope ps(ctx, MADQP_PROF_VEC);

@@ -285,3 +285,35 @@ def test_sweep_timeout_is_reported_as_a_device_fault(hip):
     with pytest.raises(M.MadQPError, match="hand-off timed out"):
         hip.norm_inf(v)
     assert hip.norm_inf(v) == 3.0  # reported once, then cleared
+
+
+@pytest.mark.parametrize("n,ld", [(4096, 4096), (5000, 5000), (4700, 4704), (9001, 9002), (300, 300)])
+def test_symmetric_matvec_from_the_lower_triangle(hip, n, ld):
+    """H x for a symmetric H from its lower triangle only (gemv.hip: madqp_symv_lower, behind mul! and the model
+    evaluation of a dense QP): the UPPER triangle is poisoned with NaN -- it must never be read -- and the product
+    equals the full one to rounding; orders that are not multiples of the 256 x 512 tiles, a leading dimension larger
+    than the order, alpha / beta, and (n = 300) the general kernel that small problems still take."""
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n))
+    Hs = G + G.T
+    x = rng.standard_normal(n)
+    y0 = rng.standard_normal(n)
+    Hd = torch.zeros((n, ld), dtype=torch.float64, device=hip.device)
+    Hd[:, :n] = torch.as_tensor(Hs, device=hip.device)
+    if n >= 4096:
+        iu = torch.triu_indices(n, n, offset=1, device=hip.device)
+        Hd[iu[0], iu[1]] = float("nan")
+    st = hip.new_state(n, 0, np.arange(0), np.arange(0))
+    z = lambda k: torch.zeros(max(k, 1), dtype=torch.float64, device=hip.device)[:k]
+    h = hip.kkt_create(n, 0, [], Hd, ld, z(0), n)  # no constraints: the KKT object is H (+ diagonal) alone
+    st.x.copy_(torch.as_tensor(x))
+    v = torch.as_tensor(x.copy(), device=hip.device)
+    w = torch.as_tensor(y0.copy(), device=hip.device)
+    hip.fill(0.0, st.reg)
+    hip.kkt_mul(h, st, w, v, -0.5, 2.0)  # w = 2 w - 0.5 (H + reg) v
+    ref = 2.0 * y0 - 0.5 * (Hs @ x)
+    assert np.max(np.abs(w.cpu().numpy() - ref)) <= 1e-12 * np.max(np.abs(ref))
+    obj = hip.kkt_eval(h, st, z(n), z(0), 0.0)
+    assert abs(obj - 0.5 * x @ Hs @ x) <= 1e-12 * abs(x @ Hs @ x)
+    assert np.max(np.abs(st.f.cpu().numpy() - Hs @ x)) <= 1e-12 * np.max(np.abs(Hs @ x))
+    hip.kkt_destroy(h)
