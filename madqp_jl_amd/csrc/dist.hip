@@ -70,6 +70,7 @@ struct Dev {
     int free_slots;  // workgroup slots the bulk updates leave to the collectives (0 = ordinary launches)
     madqp_chol* chol_nb;    // order nb: diagonal tiles
     madqp_chol* chol_last;  // order of the (partial) last tile, or nullptr
+    madqp_chol* chol_full;  // order n (P == 1): whole panels through the one-GPU panel factorisation, or nullptr
     int64_t nb, wlast;
     int32_t* ctl;           // 4 ints: tile sweeps
     bool two_streams;
@@ -213,6 +214,36 @@ int32_t dop_potrf_tile(Dev* dev, double* T, int64_t ld, int64_t w, double* buf, 
     return 0;
 }
 
+// P == 1: the panel of step k -- local column block lc, rows from k nb down -- is factored, solved and updated inside by
+// the one-GPU panel factorisation; buf <- [info, 0 | inverse 128-blocks | L_kk (w x w, ld w)], info (LAPACK's, global
+// column) merged into *info
+__global__ void dist_info_from_int_kernel(const int32_t* chol_info, double* hdr, double* info) {
+    hdr[0] = (double)*chol_info;
+    hdr[1] = 0.0;
+    if (*info == 0.0 && hdr[0] != 0.0) *info = hdr[0];
+}
+int32_t dop_panel_local(Dev* dev, double* K, int64_t ld, int64_t lc, int64_t k, int64_t nb, int64_t w, double* buf,
+                        double* info) {
+    madqp_chol* s = dev->chol_full;
+    madqp_ctx* ctx = dev->ctx;
+    if (!s) return madqp_fail(ctx, MADQP_ERR_STATE, "no order-n Cholesky object (P == 1 expected)");
+    // the factorisation addresses a column by its GLOBAL index j0 = k nb: shift the base so that this is local block lc
+    // (only the columns of the panel are touched)
+    double* base = K + (lc - k) * nb * ld;
+    int32_t r;
+    if ((r = madqp_chol_factor_begin(s, base, ld))) return r;
+    if ((r = madqp_chol_factor_panel(s, k * nb, w))) return r;
+    const int64_t nblk = (w + 127) / 128;
+    hipLaunchKernelGGL(dist_info_from_int_kernel, dim3(1), dim3(1), 0, ctx->stream, s->d_info, buf, info);
+    LAUNCH_CHECK(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(buf + 2, s->winv + (k * nb / 128) * (2 * 128 * 128), (size_t)nblk * 2 * 128 * 128 * sizeof(double),
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync(buf + 2 + nblk * 2 * 128 * 128, (size_t)w * sizeof(double), K + k * nb + lc * nb * ld,
+                                  (size_t)ld * sizeof(double), (size_t)w * sizeof(double), (size_t)w, hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+    return 0;
+}
+
 // X (rows x w, leading dimension ldx) <- X L^-T with the inverse 128-blocks W of L's diagonal (recursive, MFMA)
 int32_t trsm_range(Dev* dev, double* X, int64_t ldx, int64_t rows, int64_t rread, const double* L, int64_t ldl,
                    const double* W, int64_t j0, int64_t wd) {
@@ -262,6 +293,12 @@ int32_t dop_trsm(Dev* dev, double* X, int64_t ldx, int64_t rows, int64_t rows_re
 int32_t dop_gemv(Dev* dev, int32_t trans, int64_t rows, int64_t cols, double alpha, const double* A, int64_t lda,
                  const double* x, double beta, double* y) {
     return madqp_gemv_impl(dev->ctx, trans, rows, cols, alpha, A, lda, x, beta, y, MADQP_PROF_TRSV);
+}
+// one rank (P = Q = 1): the local matrix IS the factor and chol_full holds the inverse blocks of every panel
+// (dop_panel_local): both sweeps in the one-GPU form (chol.hip), one launch each
+int32_t dop_solve_local(Dev* dev, double* rhs) {
+    if (!dev->chol_full) return madqp_fail(dev->ctx, MADQP_ERR_STATE, "no order-n Cholesky object (1 x 1 grid expected)");
+    return madqp_chol_solve(dev->chol_full, rhs);
 }
 int32_t dop_tile_solve(Dev* dev, int32_t trans, const double* L, int64_t ld, const double* W, double* v, int64_t w,
                        double* scratch) {
@@ -379,6 +416,7 @@ void dev_destroy(Dev* dev) {
     if (!dev) return;
     if (dev->chol_nb) madqp_chol_destroy(dev->chol_nb);
     if (dev->chol_last) madqp_chol_destroy(dev->chol_last);
+    if (dev->chol_full) madqp_chol_destroy(dev->chol_full);
     if (dev->ctl) (void)hipFree(dev->ctl);
     for (auto& e : dev->ev)
         if (e) (void)hipEventDestroy(e);
@@ -443,30 +481,31 @@ extern "C" int32_t madqp_dist_create(madqp_ctx* ctx, int32_t rank, int32_t world
     int32_t r = (e == hipSuccess) ? MADQP_OK : madqp_fail(ctx, MADQP_ERR_HIP, "madqp_dist_create: %s", hipGetErrorString(e));
     if (!r && n > 0) r = madqp_chol_create(ctx, std::min(nb, n), &dev->chol_nb);
     if (!r && dev->wlast && dev->wlast != std::min(nb, n)) r = madqp_chol_create(ctx, dev->wlast, &dev->chol_last);
+    if (!r && P == 1 && n > 0) r = madqp_chol_create(ctx, n, &dev->chol_full);
     if (r) {
         dev_destroy(dev);
         return r;
     }
     if (n > 0 && n < nb) dev->nb = n;  // a single partial tile: chol_nb has order n
+    // MADQP_DIST_FORCE_RCCL=1: build the communicators and run every collective through RCCL even with one rank (a
+    // one-GPU box can then exercise the RCCL calls themselves; the id is drawn here when the caller gave none)
+    static const int force = getenv("MADQP_DIST_FORCE_RCCL") ? atoi(getenv("MADQP_DIST_FORCE_RCCL")) : 0;
+    const int32_t force_comm = (world == 1 && !ops && force) ? 1 : 0;
     madqp_dist* d = nullptr;
-    r = distcore::create(dev, rank, world, P, Q, n, nb, ops, &d);
+    r = distcore::create(dev, rank, world, P, Q, n, nb, ops, force_comm, &d);
     if (r) {
         if (d) madqp_fail(ctx, r, "madqp_dist_create: %s", d->err);
         distcore::destroy(d);
         dev_destroy(dev);
         return r == MADQP_ERR_ARG ? madqp_fail(ctx, r, "madqp_dist_create: bad grid / tile size") : r;
     }
-    // MADQP_DIST_FORCE_RCCL=1: build the communicators and run every collective through RCCL even with one rank (a
-    // one-GPU box can then exercise the RCCL calls themselves; the id is drawn here when the caller gave none)
-    static const int force = getenv("MADQP_DIST_FORCE_RCCL") ? atoi(getenv("MADQP_DIST_FORCE_RCCL")) : 0;
     ncclUniqueId own_id;
-    if (world == 1 && !ops && force) {
+    if (force_comm) {
         if (!rccl().ok || rccl().GetUniqueId(&own_id) != ncclSuccess) {
             madqp_dist_destroy(d);
             return madqp_fail(ctx, MADQP_ERR_STATE, "MADQP_DIST_FORCE_RCCL: RCCL is not available in this process");
         }
         nccl_id128 = &own_id;
-        d->force_comm = 1;
     }
     if ((world > 1 || d->force_comm) && !ops) {  // RCCL: world communicator, then one per process row / column
         if (!rccl().ok) {
@@ -559,12 +598,12 @@ inline int dk_grid(int64_t len) {
 }
 #include "kkt_kernels.inc"
 
-// S[k, :] = theta[k] * A[k, :] for k < m, zero rows up to m16
+// S[k, :] = theta[k] * A[k, :] (root != 0: sqrt(theta[k])) for k < m, zero rows up to m16
 __global__ __launch_bounds__(256) void dk_scale_rows_kernel(int64_t m, int64_t cols, const double* __restrict__ A, int64_t lda,
                                                             const double* __restrict__ theta, double* __restrict__ S,
-                                                            int64_t lds) {
+                                                            int64_t lds, int root) {
     const int64_t k = blockIdx.y;
-    const double t = (k < m) ? theta[k] : 0.0;
+    const double t = (k < m) ? (root ? sqrt(theta[k]) : theta[k]) : 0.0;
     for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cols; c += (int64_t)gridDim.x * 256)
         S[k * lds + c] = (k < m) ? t * A[k * lda + c] : 0.0;
 }
@@ -787,8 +826,10 @@ extern "C" int32_t madqp_dkkt_build(madqp_dkkt* k, const madqp_state* st) {
         if (k->m) DKL(theta_kernel, k->m, k->m, k->nx, k->d_slot, st->pr_diag, st->du_diag, k->theta);
         if (k->m16 && d->nloc) {
             const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((d->ncp + 255) / 256, 64));
+            // one rank: A_I and A_J are the same columns, so K = H + S'S with ONE operand stream S = sqrt(Theta) A
+            // (what the one-GPU assembly does, gemm_f64.hip); several ranks: K_loc = H_loc + A_I' (Theta A_J)
             hipLaunchKernelGGL(dk_scale_rows_kernel, dim3(gx, (unsigned)k->m16), dim3(256), 0, ctx->stream, k->m, d->ncp,
-                               k->AJ, k->ldaj, k->theta, k->SJ, d->ncp);
+                               k->AJ, k->ldaj, k->theta, k->SJ, d->ncp, (d->world == 1 && !d->force_comm) ? 1 : 0);
             LAUNCH_CHECK(ctx);
         }
     }
@@ -802,7 +843,8 @@ extern "C" int32_t madqp_dkkt_build(madqp_dkkt* k, const madqp_state* st) {
                                           (size_t)d->nloc, ctx->stream));
     } else {
         d->dev->prof_cls = MADQP_PROF_SYRK;
-        r = distcore::assemble_product(d, k->H, k->ldh, k->AI, k->ldai, k->SJ, d->ncp, k->m16);
+        const bool one = (d->world == 1 && !d->force_comm);  // (ld == ncp on a 1 x 1 grid)
+        r = distcore::assemble_product(d, k->H, k->ldh, one ? k->SJ : k->AI, one ? d->ncp : k->ldai, k->SJ, d->ncp, k->m16);
         d->dev->prof_cls = MADQP_PROF_POTRF_GEMM;
         if (r) return r;
     }

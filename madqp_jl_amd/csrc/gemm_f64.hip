@@ -32,6 +32,7 @@
 // XCD and its L2) walks one contiguous chunk of the table: the 64 tiles resident on an XCD
 // share 8 X panels and 8 Y panels.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -382,8 +383,29 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
     ka.ksplit = 1;
     ka.kchunk = a.K;
     ka.work = nullptr;
-    if (split_on && !batch && (int64_t)ka.ntiles * 2 <= ctx->gemm_slots && a.K >= 512) {
-        int64_t S = std::min<int64_t>(std::min<int64_t>(ctx->gemm_slots / ka.ntiles, a.K / 256), 16);
+    int64_t S_few = 0;
+    if (split_on && !batch && (int64_t)ka.ntiles * 2 > ctx->gemm_slots && (int64_t)ka.ntiles < 8 * ctx->gemm_slots &&
+        a.K >= 4096) {
+        // A launch of a few rounds of LONG tiles (the wide updates of the lazy distributed schedule, whose tile-column
+        // width is the grid's tile and cannot be tuned to fill the rounds as chol.hip tunes its panels: 560 tiles of
+        // K = 38 000 take two rounds of 11 ms, the second one a tenth full, and whoever shares a CU with a finished
+        // workgroup runs on alone): cut K into S chunks -- more, shorter rounds.  S minimises the model
+        //   rounds(S) x (tile time of K/S + fixed cost of a tile) + pass over the S x tiles partial tiles
+        // (microseconds: 0.216 per unit of K, 10 per tile, 0.05 per partial tile).  With short tiles (n_x = 5 000:
+        // K = 2 000) the model and the measurement agree that it does not pay; those launches are left alone.
+        auto cost = [&](int64_t S) {
+            const double rounds = std::ceil((double)ka.ntiles * (double)S / (double)ctx->gemm_slots);
+            return rounds * (0.216 * (double)a.K / (double)S + 10.0) + 0.05 * (double)S * (double)ka.ntiles;
+        };
+        double best = cost(1) * 0.97;
+        for (int64_t S = 2; S <= 16 && a.K / S >= 2048; ++S)
+            if (cost(S) < best) {
+                best = cost(S);
+                S_few = S;
+            }
+    }
+    if (split_on && !batch && (((int64_t)ka.ntiles * 2 <= ctx->gemm_slots && a.K >= 512) || S_few)) {
+        int64_t S = S_few ? S_few : std::min<int64_t>(std::min<int64_t>(ctx->gemm_slots / ka.ntiles, a.K / 256), 16);
         if (S >= 2) {
             const int64_t chunk = ((a.K + S - 1) / S + BK - 1) / BK * BK;
             S = (a.K + chunk - 1) / chunk;

@@ -104,6 +104,22 @@ static int32_t dop_potrf_tile(Dev*, double* T, int64_t ld, int64_t w, double* bu
     return 0;
 }
 static int32_t dop_trsm(Dev*, double* X, int64_t ldx, int64_t rows, int64_t, const double* L, int64_t ldl, const double*,
+                        int64_t w);
+// P == 1: tile factorisation + the solve of the rows below, as one step (the HIP build runs chol.hip's panel code here)
+static int32_t dop_panel_local(Dev* dev, double* K, int64_t ld, int64_t lc, int64_t k, int64_t nb, int64_t w, double* buf,
+                               double* info) {
+    double* T = K + k * nb + lc * nb * ld;
+    int32_t r = dop_potrf_tile(dev, T, ld, w, buf, k * nb, info);
+    if (r) return r;
+    // rows below the tile: everything this rank holds (P == 1: all rows of the matrix) -- the caller's local row count
+    // is not known here, so the extent comes from the leading dimension's owner: dist_core passes ld >= rows; the
+    // padded rows are zero and stay zero
+    const int64_t nblk = (w + 127) / 128;
+    const double* L = buf + 2 + nblk * 2 * 128 * 128;
+    const int64_t below = ld - (k * nb + w);
+    return below > 0 ? dop_trsm(dev, T + w, ld, below, below, L, w, nullptr, w) : 0;
+}
+static int32_t dop_trsm(Dev*, double* X, int64_t ldx, int64_t rows, int64_t, const double* L, int64_t ldl, const double*,
                         int64_t w) {
     for (int64_t i = 0; i < rows; ++i)
         for (int64_t j = 0; j < w; ++j) {
@@ -131,6 +147,10 @@ static int32_t dop_gemv(Dev*, int32_t trans, int64_t rows, int64_t cols, double 
     }
     return 0;
 }
+static int32_t dop_tile_solve(Dev*, int32_t trans, const double* L, int64_t ld, const double*, double* v, int64_t w,
+                              double*);
+static madqp_dist* g_solve_local_of = nullptr;  // (the CPU stand-in needs the matrix: set by madqp_distcpu_solve)
+static int32_t dop_solve_local(Dev* dev, double* rhs);
 static int32_t dop_tile_solve(Dev*, int32_t trans, const double* L, int64_t ld, const double*, double* v, int64_t w,
                               double*) {
     if (!trans) {
@@ -196,12 +216,18 @@ static int32_t dop_group_pack(Dev*, double* out, const double* loc, int64_t I0, 
 
 #include "../../madqp_jl_amd/csrc/dist_core.inc"
 
+static int32_t dop_solve_local(Dev* dev, double* rhs) {  // one rank: forward and backward substitution over the whole factor
+    madqp_dist* d = g_solve_local_of;
+    int32_t r = dop_tile_solve(dev, 0, d->K, d->ld, nullptr, rhs, d->n, nullptr);
+    return r ? r : dop_tile_solve(dev, 1, d->K, d->ld, nullptr, rhs, d->n, nullptr);
+}
+
 extern "C" {
 int32_t madqp_distcpu_create(int32_t rank, int32_t world, int32_t P, int32_t Q, int64_t n, int64_t nb,
                              const madqp_comm_ops* ops, madqp_dist** out) {
     if (!out || (world > 1 && !ops)) return MADQP_ERR_ARG;
     Dev* dev = new Dev();
-    int32_t r = distcore::create(dev, rank, world, P, Q, n, nb, ops, out);
+    int32_t r = distcore::create(dev, rank, world, P, Q, n, nb, ops, 0, out);
     if (r) {
         distcore::destroy(*out);
         *out = nullptr;
@@ -227,7 +253,10 @@ int32_t madqp_distcpu_matrix(madqp_dist* d, double** K, int64_t* ld) {
     return 0;
 }
 int32_t madqp_distcpu_factor(madqp_dist* d, int32_t* info) { return distcore::factor(d, info); }
-int32_t madqp_distcpu_solve(madqp_dist* d, double* rhs) { return distcore::solve(d, rhs); }
+int32_t madqp_distcpu_solve(madqp_dist* d, double* rhs) {
+    g_solve_local_of = d;
+    return distcore::solve(d, rhs);
+}
 int32_t madqp_distcpu_bytes_sent(madqp_dist* d, int64_t* b) {
     *b = d->bytes_sent;
     return 0;
