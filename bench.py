@@ -462,7 +462,9 @@ def measure(args, M, be, world, seed, mode, max_ncorr=None, steps=None, warmup=N
                last_trace={k: solver.trace[-1][k] for k in ("k", "inf_pr", "inf_du", "inf_compl", "mu")}
                if solver.trace else None)
     if mode == "grid":
-        mem = 8 * (grid.ld * grid.ncp * (2 if dq.H is not None else 1) + dq.A_I.numel() + 2 * dq.A_J.numel())
+        T = (nx + grid.nb - 1) // grid.nb  # + the stored operands of the lazy updates (csrc/dist_core.inc: XW, YW)
+        stored = (grid.ld * T * grid.nb if grid.Q > 1 else 0) + (grid.ncp * T * grid.nb if grid.P * grid.Q > 1 else 0)
+        mem = 8 * (grid.ld * grid.ncp * (2 if dq.H is not None else 1) + dq.A_I.numel() + 2 * dq.A_J.numel() + stored)
         res["layout"] = dict(kind="P x Q block-cyclic, nothing of order n^2 or m n replicated", grid=[grid.P, grid.Q],
                              tile=grid.nb, local_matrix=[grid.mloc, grid.nloc],
                              rank0_matrix_bytes=int(mem), bytes_broadcast_by_rank0=grid.bytes_sent())
