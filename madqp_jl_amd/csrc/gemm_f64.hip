@@ -393,7 +393,7 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
         //   rounds(S) x (tile time of K/S + fixed cost of a tile) + pass over the S x tiles partial tiles
         // (microseconds: 0.216 per unit of K, 10 per tile, 0.05 per partial tile).  With short tiles (n_x = 5 000:
         // K = 2 000) the model and the measurement agree that it does not pay; those launches are left alone.
-        auto cost = [&](int64_t S) {
+        auto cost = [&](int64_t S) {  // (an extra term for the drain of the last round was tried: 0.5 .. 2 tile times cost 0 .. 5 ms)
             const double rounds = std::ceil((double)ka.ntiles * (double)S / (double)ctx->gemm_slots);
             return rounds * (0.216 * (double)a.K / (double)S + 10.0) + 0.05 * (double)S * (double)ka.ntiles;
         };
