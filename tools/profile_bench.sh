@@ -1,10 +1,10 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of bench.py.
-# Usage: tools/profile_bench.sh <tag> [bench args...]; writes gpurun_out/prof_<tag>_*/
+# Usage: [PROF_DIR=/tmp/prof] tools/profile_bench.sh <tag> [bench args...]; writes $PROF_DIR/prof_<tag>_*/ (default gpurun_out/)
 set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out
+OUT=${PROF_DIR:-$ROOT/gpurun_out}   # raw traces are large: point PROF_DIR at /tmp and keep only the summaries
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH_ARGS=("$@")

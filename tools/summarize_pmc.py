@@ -12,14 +12,16 @@ import csv
 import glob
 import json
 import shutil
+import os
 import sys
 
+PROF = os.environ.get("PROF_DIR", "gpurun_out")  # where tools/profile_bench.sh wrote its passes
 tag = sys.argv[1]
 out = {}
 
 
 def rows(kind):
-    f = glob.glob(f"gpurun_out/prof_{tag}_{kind}/*/*_counter_collection.csv")
+    f = glob.glob(f"{PROF}/prof_{tag}_{kind}/*/*_counter_collection.csv")
     return list(csv.DictReader(open(f[0]))) if f else []
 
 
@@ -80,7 +82,7 @@ m = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
 # HBM-bound kernels: achieved rate = PMC bytes (read corrected + written) / duration of the same dispatches
 # in the un-instrumented --kernel-trace --stats pass (average duration x dispatch count)
 stats = {}
-for f in glob.glob(f"gpurun_out/prof_{tag}_stats/*/*_kernel_stats.csv"):
+for f in glob.glob(f"{PROF}/prof_{tag}_stats/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         k = short(r["Name"])
         if k:
@@ -101,6 +103,6 @@ bench_args = sys.argv[4] if len(sys.argv) > 4 else "(defaults: --steps 3 --warmu
 out["config"] = dict(nx=nx, m=m, command=f"rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-cpu-baseline {bench_args} "
                                          f"[nx={nx}, m={m}]; one pass per counter group (tools/profile_bench.sh)")
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
-for f in glob.glob(f"gpurun_out/prof_{tag}_stats/*/*_kernel_stats.csv"):
+for f in glob.glob(f"{PROF}/prof_{tag}_stats/*/*_kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_bench50k_kernel_stats.csv")
 print(json.dumps(out, indent=1)[:3000])
