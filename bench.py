@@ -634,9 +634,33 @@ class LastResortReporter:
             self.p = None
 
 
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner when
+    its first communicator comes up): from here on file descriptor 1 is stderr, and only `emit_json` reaches the
+    stdout the launcher gave this process."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
     args = parse()
     reporter = LastResortReporter(int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0)
+    protect_stdout()  # (after the reporter child exists: it keeps the real stdout for the held line)
     import torch
     import torch.distributed as dist
 
@@ -650,7 +674,7 @@ def main():
     be = M.HipBackend(local_rank)
     nx, m = args.nx, args.m
     if args.cpu_full:
-        print(json.dumps(cpu_full_size(args, M, be)), flush=True)
+        emit_json(cpu_full_size(args, M, be))
         be.close()
         return
     mode = {"local": "local", "distributed": "grid", None: "local" if world == 1 else "grid"}[args.kkt]
@@ -680,7 +704,7 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, nx, m, M, be)
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit_json(out)
     else:
         # N > 1: the headline is ONE QP over all GPUs (strong scaling, north_star's 2-D block-cyclic distributed
         # Cholesky).  The independent-QPs number (one QP per GPU, no collective in the data path) is measured first and
@@ -702,7 +726,7 @@ def main():
                     return
                 state["printed"] = True
                 if rank == 0:
-                    print(json.dumps(obj), flush=True)
+                    emit_json(obj)
                 reporter.done()
 
         def fallback(msg):
