@@ -96,3 +96,29 @@ def test_watchdog_measures_silence_not_the_length_of_the_run():
     dog.stop()
     time.sleep(0.3)
     assert len(fired) == 1
+
+
+def test_only_the_json_line_reaches_stdout():
+    """The contract is ONE JSON line on stdout, and libraries write there too (RCCL prints a version banner when its
+    first communicator comes up -- seen in the forced one-rank run of round 3): after bench.protect_stdout() file
+    descriptor 1 is stderr and only bench.emit_json reaches the launcher's stdout."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent('''
+        import os, sys
+        sys.path.insert(0, %r)
+        import bench
+        bench.protect_stdout()
+        os.write(1, b"RCCL version : 2.26.6-HEAD\\n")   # a C library writing to fd 1
+        print("a stray print")                             # Python's sys.stdout is fd 1 too
+        bench.emit_json({"metric": "x", "value": 1})
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "x", "value": 1}, out.stdout
+    assert "RCCL version" in out.stderr and "a stray print" in out.stderr
