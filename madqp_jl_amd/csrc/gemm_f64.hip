@@ -263,6 +263,9 @@ struct TableKey {
 struct TableVal {
     int32_t* d;
     int32_t n;
+    std::vector<int64_t> mask;  // the column ranges / per-column first rows the table was built for: the key holds only
+                                // their hash, a hit is a hit only if these agree (the distributed path makes hundreds
+                                // of masks per context)
 };
 // per-context cache of tile tables.  A context is used by one host thread at a time, different
 // contexts may live on different threads (batch sharding): the outer map is guarded by a mutex,
@@ -323,8 +326,16 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
     TableKey key{tiles_m, tiles_n,
                  (a.lower_only ? 1 : 0) | ((a.M % BM) != 0 ? 2 : 0) | ((a.N % BN) != 0 ? 4 : 0),
                  a.lower_only ? a.diag_off : 0, cols_hash};
+    std::vector<int64_t> mask;
+    if (cols) mask.assign(cols, cols + 2 * ncols);
+    if (a.tile_row0) mask.assign(a.tile_row0, a.tile_row0 + tiles_n);
     auto& cache = tables_of(ctx);
     auto it = cache.find(key);
+    while (it != cache.end() && it->second.mask != mask) {  // same hash, another mask: walk to a free or matching key
+        key.cols_hash += 0x9E3779B97F4A7C15ull;
+        if (key.cols_hash == 0) key.cols_hash = 1;
+        it = cache.find(key);
+    }
     if (it == cache.end()) {
         std::vector<int32_t> tab;
         tab.reserve((size_t)tiles_m * tiles_n);
@@ -356,7 +367,7 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
                         if (!active(tm, tn) || is_edge(tm, tn)) continue;
                         tab.push_back((int32_t)((tm << 16) | tn));
                     }
-        TableVal v{nullptr, (int32_t)tab.size()};
+        TableVal v{nullptr, (int32_t)tab.size(), mask};
         if (!tab.empty()) {
             HIP_TRY(ctx, hipMalloc(&v.d, tab.size() * sizeof(int32_t)));
             HIP_TRY(ctx, hipMemcpyAsync(v.d, tab.data(), tab.size() * sizeof(int32_t),

@@ -81,6 +81,9 @@ def check_lookahead_order(schedule, p, q, P, Q, T):
     (1, 1, 600, 128, 2, 29551),   # one rank: operands read in place from the factored panel, nothing packed or sent
     (2, 4, 1400, 128, 2, 29553),  # the 8-GPU grid of BASELINE configs[4]: gcd(P, Q) = 2; 11 tiles, 6 groups on 8 ranks
     (2, 2, 1100, 128, 0, 29555),  # default group (4096 rows > n): ONE group, everything collected on rank 0
+    (3, 2, 1100, 128, 2, 29557),  # P > Q: a rank's next tile column is several steps away from the panel
+    (1, 3, 900, 128, 3, 29559),   # one process row of three: whole-panel factorisation, operands gathered locally
+    (4, 1, 800, 128, 2, 29561),   # one process column of four: row operands read in place, column operands stored
 ])
 def test_distributed_cholesky_2d(cpuref, tmp_path, P, Q, n, nb, group, port):
     world = P * Q
