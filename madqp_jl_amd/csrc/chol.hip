@@ -62,21 +62,22 @@ __device__ __forceinline__ double fast_rsqrt(double a) {
     return h + h;
 }
 
-// One wave: Cholesky of the 16 x 16 sub-block at (b, b) of S and the inverse of its factor, as 16
-// rank-1 steps on the MFMA unit.  The (symmetric) sub-block and W live in the accumulator layout of
-// v_mfma_f64_16x16x4_f64 (lane l, register v: row (l>>4) + 4v, column l&15).  Row k of the block
-// therefore sits in register k>>2 of the 16 lanes of group g = k&3 -- exactly the lanes that feed
-// k-slot g of BOTH operands -- so the scaled row (= column l_k, by symmetry) is the A- and the
-// B-operand of  D -= l_k l_k'  as it stands: no cross-lane traffic except one v_readlane for the
-// pivot.  W = L^-1 follows from the same steps applied to the identity (W[k,:] *= 1/l_kk,
-// W[i,:] -= l_ik W[k,:], i > k), a second MFMA per step off the critical path.
-// (The previous version kept a row per lane and broadcast with 2 x 135 v_readlane: 5.0 us per
-// sub-block, measured with tools/potf2_probe; the chain here is readlane -> rsqrt -> mul -> mfma.)
-// Writes L (lower) back to S and W to Wd[r*WD_LD + c] (zero above the diagonal).
-__device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int b,
-                                                     double* __restrict__ Wd,
-                                                     int32_t* __restrict__ info, int32_t col0,
-                                                     int lane) {
+// One wave: Cholesky of the 16 x 16 sub-block at (b, b) of S and the inverse of its factor, in four RANK-4 steps on the
+// MFMA unit.  The (symmetric) sub-block and W live in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l,
+// register v: row (l>>4) + 4v, column l&15), so the four rows 4p .. 4p+3 of the block are ONE register (A[p]: lane
+// group hi holds row 4p + hi) -- and one register per lane group is exactly what a k-slot of the instruction takes: the
+// four scaled rows of a 4-row group are the A- and the B-operand of D -= sum_j l_j l_j' as they stand, ONE dependent
+// MFMA per four pivots.  (Round 1 kept a row per lane and broadcast with 2 x 135 v_readlane: 5.0 us per sub-block;
+// rounds 1-2 ran 16 rank-1 MFMA steps, 3.08 us: every pivot paid the round trip through a dependent MFMA; this form
+// 2.84 us -- what remains is 16 x (read-lane -> rsqrt chain -> scale -> read-lane -> fma) on the vector ALU, ~175 ns
+// each, tools/potf2_probe.)  The 4 x 4 elimination inside the group runs
+// on the vector ALU, on all 64 lanes redundantly: the four rows (and the four rows of W) are first replicated to every
+// lane group (one cross-lane read each), after which a pivot needs two read-lanes, the rsqrt chain and one fma per
+// later row.  Every update is one fused multiply-add, in the order of the pivots; W = L^-1 follows from the same steps
+// applied to the identity (W[k,:] *= 1/l_kk, W[i,:] -= l_ik W[k,:], i > k).  Writes L (lower) back to S and W to
+// Wd[r*WD_LD + c] (zero above the diagonal).
+__device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int b, double* __restrict__ Wd,
+                                                        int32_t* __restrict__ info, int32_t col0, int lane) {
     const int lo = lane & 15, hi = lane >> 4;
     double4_t A, W;
 #pragma unroll
@@ -86,34 +87,47 @@ __device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int
         W[v] = (row == lo) ? 1.0 : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < SB; ++k) {
-        const int g = k & 3, v = k >> 2;
-        const double arow = A[v];  // row k of the block in the lanes of group g
-        double akk = readlane_f64(arow, 16 * g + k);
-        if (!(akk > 0.0)) {  // not positive definite (or NaN): record the first column, go on
-            if (lane == 0) atomicCAS(info, 0, col0 + b + k + 1);
-            akk = 1.0;
+    for (int p = 0; p < 4; ++p) {
+        const int k0 = 4 * p;
+        double R[4], V[4], l[4], w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // rows k0 + j of A and of W, in every lane group
+            R[j] = __shfl(A[p], lo + 16 * j, 64);
+            V[j] = __shfl(W[p], lo + 16 * j, 64);
         }
-        // straight-line selects only: every instruction here is on the critical chain of the block
-        const double rd = fast_rsqrt(akk);
-        const double d = akk * rd;  // l_kk
-        const double t = arow * rd;
-        const bool ing = (hi == g), gt = ing && (lo > k), eq = ing && (lo == k);
-        double lk = gt ? t : 0.0;  // l_k over the lanes of group g; exact zeros above the diagonal
-        lk = eq ? d : lk;
-        if (ing && lo >= k) S[(b + k) * LDS_LD + b + lo] = lk;
-        A = __builtin_amdgcn_mfma_f64_16x16x4f64(-lk, lk, A, 0, 0, 0);
-        // W <- E_k W: row k scaled by 1/l_kk in place, then W[i,:] -= l_ik W[k,:] for i > k.  (Folding
-        // the scaling into the product, a = l_k - e_k, cancels catastrophically for large pivots.)
-        const double wk = ing ? W[v] * rd : 0.0;
-        W[v] = ing ? wk : W[v];
-        const double aw = gt ? t : 0.0;
-        W = __builtin_amdgcn_mfma_f64_16x16x4f64(-aw, wk, W, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j;
+            double akk = readlane_f64(R[j], k);
+            if (!(akk > 0.0)) {  // not positive definite (or NaN): record the first column, go on
+                if (lane == 0) atomicCAS(info, 0, col0 + b + k + 1);
+                akk = 1.0;
+            }
+            const double rd = fast_rsqrt(akk);
+            const double d = akk * rd;  // l_kk
+            const double t = R[j] * rd;
+            double lk = (lo > k) ? t : 0.0;  // exact zeros above the diagonal
+            lk = (lo == k) ? d : lk;
+            l[j] = lk;
+            w[j] = V[j] * rd;  // row k of W, scaled
+            if (hi == j && lo >= k) S[(b + k) * LDS_LD + b + lo] = lk;
+#pragma unroll
+            for (int j2 = j + 1; j2 < 4; ++j2) {  // the later rows of the group: A[i,:] -= l_ik l_k', W[i,:] -= l_ik w_k
+                const double s = readlane_f64(lk, k0 + j2);
+                R[j2] = __builtin_fma(-s, lk, R[j2]);
+                V[j2] = __builtin_fma(-s, w[j], V[j2]);
+            }
+        }
+        const double lsel = (hi == 0) ? l[0] : (hi == 1) ? l[1] : (hi == 2) ? l[2] : l[3];
+        const double wsel = (hi == 0) ? w[0] : (hi == 1) ? w[1] : (hi == 2) ? w[2] : w[3];
+        A = __builtin_amdgcn_mfma_f64_16x16x4f64(-lsel, lsel, A, 0, 0, 0);
+        const double aw = (lo >= k0 + 4) ? lsel : 0.0;  // rows below the group; its own rows were done above
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(-aw, wsel, W, 0, 0, 0);
+        W[p] = wsel;  // rows k0 .. k0+3 of W are final
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) Wd[(hi + 4 * v) * WD_LD + lo] = W[v];
 }
-
 // Cholesky of one nb x nb (nb <= 128) diagonal block, resident in LDS, and the inverse of its
 // factor -- blocked by 16 so that everything off the 16 x 16 diagonal sub-blocks is
 // v_mfma_f64_16x16x4_f64 work with operands read straight from the LDS image:
