@@ -49,6 +49,8 @@ struct BQ {  // device view of the batch (by value in the kernel arguments); pro
     double *f, *c, *jacl, *reg, *pr_diag, *du_diag, *d, *p, *w1, *w2;
     double *l_diag, *l_lower, *u_diag, *u_lower, *corr_lb, *corr_ub;
     double *theta, *t, *u, *K, *S, *winv, *tmp, *tn;
+    double* sym;      // scratch of the symmetric H products (batch_wg.inc: wg_symv_lower), nullptr: full-matrix passes
+    int64_t sym_len;  // doubles per problem
     double* scal;
     int32_t *status, *iters, *info, *retry_skip;
     madqp_mpc_options opt;
@@ -89,7 +91,7 @@ __device__ __forceinline__ madqp_state state_of(const BQ& q, int64_t b) {
 // per-problem pointers that are not part of madqp_state
 struct Prob {
     const double *H, *A, *qv, *rhs;
-    double *theta, *t, *u, *K, *S, *winv, *tmp, *tn, *w1, *scal;
+    double *theta, *t, *u, *K, *S, *winv, *tmp, *tn, *w1, *scal, *sym;
     double c0;
 };
 __device__ __forceinline__ Prob prob_of(const BQ& q, int64_t b) {
@@ -106,6 +108,7 @@ __device__ __forceinline__ Prob prob_of(const BQ& q, int64_t b) {
     p.winv = q.winv + b * q.nblk * WBLK;
     p.tmp = q.tmp + b * q.npad;
     p.tn = q.tn ? q.tn + b * q.n : nullptr;
+    p.sym = q.sym ? q.sym + b * q.sym_len : nullptr;
     p.w1 = q.w1 + b * q.ntot;
     p.scal = q.scal + b * S_COUNT;
     p.c0 = q.c0[b];
@@ -310,6 +313,11 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
     BALLOC(q.winv, B * q.nblk * WBLK, true);  // potf2_inv_kernel writes the lower parts only
     BALLOC(q.tmp, B * q.npad);
     if (normal) BALLOC(q.tn, B * q.n);
+    {  // H products from the lower triangle (MADQP_BATCH_SYMV=0: full-matrix passes)
+        static const bool symv = !(getenv("MADQP_BATCH_SYMV") && atoi(getenv("MADQP_BATCH_SYMV")) == 0);
+        q.sym_len = (512 / 64 + 1) * 512;  // SYM_DOUBLES of the widest workgroup program
+        if (symv && data->H && nx > 0 && nx <= 512) BALLOC(q.sym, B * q.sym_len);
+    }
     BALLOC(q.scal, B * S_COUNT, true);
     BALLOC(q.status, B, true);
     BALLOC(q.iters, B, true);
