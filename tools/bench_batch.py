@@ -22,12 +22,12 @@ def batch_roofline(nx, m, iters, seconds, max_ncorr=0):
     MFMA flops per problem-iteration: assembly m nx^2 + Cholesky nx^3/3.
     Algorithmic HBM bytes per problem-iteration: every matrix pass the iteration needs at 8 B per entry, a pass over a
     triangle counted as half a matrix -- per solve_system (two at max_ncorr = 0): A' u, A dx, A' v_y (m nx each; the
-    residual check reuses the solve's A dx), H v (nx^2), two sweeps over L (nx^2/2 each); per iteration besides:
-    jtprod A' y (m nx), the model evaluation H x + A x (nx^2 + m nx); assembly: H lower (nx^2/2) in, the scaled operand
+    residual check reuses the solve's A dx), H v from the lower triangle (nx^2/2), two sweeps over L (nx^2/2 each); per
+    iteration besides: jtprod A' y (m nx), the model evaluation H x + A x (nx^2/2 + m nx); assembly: H lower (nx^2/2) in, the scaled operand
     sqrt(Theta) A written and read (2 m nx), K lower out (nx^2/2); Cholesky: K in, L out (nx^2/2 each)."""
     flops = m * nx * nx + nx ** 3 / 3.0
     solves = 2 + max_ncorr
-    doubles = solves * (3 * m * nx + nx * nx + nx * nx) + (m * nx) + (nx * nx + m * nx) + (nx * nx // 2 + 2 * m * nx + nx * nx // 2) + nx * nx
+    doubles = solves * (3 * m * nx + nx * nx // 2 + nx * nx) + (m * nx) + (nx * nx // 2 + m * nx) + (nx * nx // 2 + 2 * m * nx + nx * nx // 2) + nx * nx
     it_per_s = iters / seconds
     tf, gbs = it_per_s * flops * 1e-12, it_per_s * 8.0 * doubles * 1e-9
     return {"flops_per_problem_iteration": flops, "algorithmic_bytes_per_problem_iteration": 8.0 * doubles,
