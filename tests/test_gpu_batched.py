@@ -36,7 +36,10 @@ def check_against_oracle(qps, res, **okw):
 
 
 @pytest.mark.parametrize("n,m,B,family", [(64, 24, 12, "wigner"), (40, 16, 6, "lp"), (300, 120, 5, "wigner"),
-                                          (130, 1, 3, "wigner")])
+                                          (130, 1, 3, "wigner"),
+                                          # H products: from the lower triangle up to n_x = 512 (all eight 64-column chunks
+                                          # at 512, a partial last chunk at 300 above), the full-matrix passes beyond
+                                          (512, 200, 3, "wigner"), (576, 64, 2, "wigner")])
 def test_batched_vs_oracle(hip, n, m, B, family):
     qps = [Q.synthetic_qp(500 + 7 * i + n, n, m, family) for i in range(B)]
     s = M.BatchedMPCSolver([to_device(q, hip) for q in qps], hip, regularization=REG)

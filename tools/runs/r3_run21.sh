@@ -1,0 +1,2 @@
+set -e
+python -m pytest tests/test_gpu_batched.py -x -q 2>&1 | tail -3
