@@ -1,0 +1,10 @@
+set -e
+mkdir -p gpurun_out
+python -m pytest tests -x -q -m gpu > gpurun_out/r31_tests.log 2>&1 || { tail -30 gpurun_out/r31_tests.log; exit 1; }
+tail -2 gpurun_out/r31_tests.log
+python bench.py --steps 10 --warmup 2 > gpurun_out/r31_bench_default.json 2> gpurun_out/r31_bench_default.err
+tail -1 gpurun_out/r31_bench_default.json | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline_hbm']['frac'], d['cpu_baseline']['value'], d['extras']['batch_1024x512x256']['value'])"
+bash tools/runs/r3_batch_prof.sh
