@@ -154,6 +154,7 @@ int32_t madqp_gemv_impl(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t col
 
 // y(n) = alpha H x + beta y for a symmetric H (row r at H + r*ldh) from its LOWER triangle only: half the bytes of the
 // general product (gemv.hip)
+bool madqp_symv_lower_reads_triangle(int64_t n, const double* H, int64_t ldh);
 int32_t madqp_symv_lower(madqp_ctx* ctx, int64_t n, double alpha, const double* H, int64_t ldh, const double* x,
                          double beta, double* y, int prof_cls);
 

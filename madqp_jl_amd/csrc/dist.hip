@@ -783,6 +783,10 @@ static int32_t dk_H_partial(madqp_dkkt* k, double alpha, const double* x) {
     madqp_ctx* ctx = k->ctx;
     if (!k->H || d->mloc == 0 || d->nloc == 0) return MADQP_OK;
     const int64_t nb = d->nb;
+    // one rank: the local tiles ARE the lower triangle of H (ld = ldh), x and the accumulator are whole vectors -- one
+    // pass over the triangle (gemv.hip) instead of two over every tile column (8 ms per iteration at n = 50 000)
+    if (d->world == 1 && !d->force_comm && madqp_symv_lower_reads_triangle(d->n, k->H, k->ldh))
+        return madqp_symv_lower(ctx, d->n, alpha, k->H, k->ldh, x, 1.0, k->gn, MADQP_PROF_GEMV);
     {
         ProfScope ps(ctx, MADQP_PROF_VEC);
         DKL(dk_gather_kernel, d->mloc, d->mloc, nb, (int64_t)d->P, (int64_t)d->p, d->n, x, k->xr);

@@ -232,16 +232,20 @@ static_assert(SY_TC == 2 * SY_TR, "symv_reduce_kernel's first row tile of a colu
 
 // y(n) = alpha H x + beta y with H symmetric, n x n, row (= column) r at H + r*ldh: the lower triangle is read.
 // Small or unaligned operands go through the general product (both triangles).
+// true: madqp_symv_lower touches the lower triangle only (a caller that holds nothing else must ask)
+bool madqp_symv_lower_reads_triangle(int64_t n, const double* H, int64_t ldh) {
+    // below ~12 000 the 256 x 512 tiles are fewer than the chip's workgroup slots and the second pass is not paid back
+    // (n = 5 000: 6.31 against 6.18 ms per iteration; n = 50 000: 1316 against 1323.5)
+    static const int64_t nmin = getenv("MADQP_SYMV_MIN") ? atoll(getenv("MADQP_SYMV_MIN")) : 12288;
+    const bool vec = (((uintptr_t)H) & 15) == 0 && (ldh % 2 == 0);
+    return n >= nmin && vec;
+}
 int32_t madqp_symv_lower(madqp_ctx* ctx, int64_t n, double alpha, const double* H, int64_t ldh, const double* x,
                          double beta, double* y, int prof_cls) {
     ARG_TRY(ctx, ctx != nullptr && n >= 0);
     if (n == 0) return MADQP_OK;
     ARG_TRY(ctx, H && x && y && ldh >= n);
-    // below ~12 000 the 256 x 512 tiles are fewer than the chip's workgroup slots and the second pass is not paid back
-    // (n = 5 000: 6.31 against 6.18 ms per iteration; n = 50 000: 1316 against 1323.5)
-    static const int64_t nmin = getenv("MADQP_SYMV_MIN") ? atoll(getenv("MADQP_SYMV_MIN")) : 12288;
-    const bool vec = (((uintptr_t)H) & 15) == 0 && (ldh % 2 == 0);
-    if (n < nmin || !vec) return madqp_gemv_impl(ctx, 0, n, n, alpha, H, ldh, x, beta, y, prof_cls);
+    if (!madqp_symv_lower_reads_triangle(n, H, ldh)) return madqp_gemv_impl(ctx, 0, n, n, alpha, H, ldh, x, beta, y, prof_cls);
     const int64_t nrt = (n + SY_TR - 1) / SY_TR, nct = (n + SY_TC - 1) / SY_TC;
     int32_t r = madqp_work_reserve(ctx, (size_t)(nrt + nct) * n * sizeof(double));
     if (r) return r;
