@@ -159,11 +159,42 @@ struct Potf2Batch {  // problem blockIdx.x: pointer strides (doubles / ints); sk
 #define P2_QUIET_WAVE 4
 #endif
 constexpr int P2_QUIET = P2_QUIET_WAVE;  // -1: every helper wave works in the trailing phase
-constexpr int P2_THREADS = 512;  // wave 0: the chain of 16 x 16 diagonal factorisations; waves 1..7: everything else
-// (1024 threads: loads and stores faster, the steps slower -- 45.2 vs 44.4 us)
+// 512 threads: wave 0 runs the chain of 16 x 16 diagonal factorisations, waves 1..7 everything else
 constexpr int P2_S_DOUBLES = NB * LDS_LD;         // S[c*LDS_LD + r] = element (r, c)
 constexpr int P2_WD_DOUBLES = NSB * SB * WD_LD;   // inverse diagonal sub-blocks
-// the whole workgroup (P2_THREADS threads) calls this; S and Wd are its LDS work areas
+// The helper waves' tile products of step J, NHE waves sharing them round-robin: waves[J][hr] = up to eight entries of
+// 8 bits, 0xFF ends the list; bit 6: 0 = trailing tile (K = bits 5..3, I = bits 2..0), 1 = inverse tile (I, J').
+// Drawn at compile time: enumerating the 34 tiles of a step in every wave (loop, modulo, three branches per tile) cost
+// more instruction issue and fetch than the products themselves -- the phase got SLOWER with more helper waves.
+template <int NHE>
+struct P2Lists {
+    static_assert(NHE >= 5, "at most 34 tiles per step: seven entries and the end mark per wave");
+    unsigned long long waves[NB / 16][NHE];
+    constexpr P2Lists() : waves{} {
+        constexpr int N = NB / 16;
+        for (int J = 0; J < N; ++J) {
+            int cnt[NHE] = {};
+            for (int h = 0; h < NHE; ++h) waves[J][h] = ~0ull;
+            int c = 0;
+            auto put = [&](int e) {
+                const int h = c % NHE;
+                waves[J][h] = (waves[J][h] & ~(0xFFull << (8 * cnt[h]))) | ((unsigned long long)e << (8 * cnt[h]));
+                ++cnt[h];
+                ++c;
+            };
+            for (int K = J + 1; K < N; ++K)
+                for (int I = K; I < N; ++I)
+                    if (!(K == J + 1 && I == J + 1)) put(K * 8 + I);
+            for (int I = J + 1; I < N; ++I)
+                for (int Jp = 0; Jp <= J; ++Jp) put(64 + I * 8 + Jp);
+        }
+    }
+};
+template <int NHE>
+__device__ __constant__ const P2Lists<NHE> p2_lists{};
+
+// the whole workgroup (NT threads: 512, or 1024 in probe builds) calls this; S and Wd are its LDS work areas
+template <int NT>
 __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t lda, int nb,
                                                double* __restrict__ Wcm, double* __restrict__ Wrm,
                                                int32_t* __restrict__ info, int32_t col0,
@@ -174,7 +205,7 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
     P2_STAMP(0);
     if (!tile_in_lds) {  // lower triangle -> LDS: row r = tid & 127, columns (tid >> 7) + CG*i; all loads of a thread in flight at
         // once (one HBM / L2 latency; the kernel runs alone on its CU, registers are free)
-        constexpr int CG = P2_THREADS / NB;
+        constexpr int CG = NT / NB;
         const int r = tid & (NB - 1), c0 = tid >> 7;
         double v[NB / CG];
 #pragma unroll
@@ -241,7 +272,7 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
 #pragma unroll
         for (int v = 0; v < 4; ++v) S[(SB * I + hi + 4 * v) * LDS_LD + SB * Jp + lo] = -R[v];
     };
-    constexpr int NWV = P2_THREADS / 64, NH = NWV - 1;  // waves; helper waves 1..NH
+    constexpr int NWV = NT / 64, NH = NWV - 1;  // waves; helper waves 1..NH
     if (wave == 0) diag16_factor_invert(S, 0, Wd, info, col0, lane);
     __syncthreads();
     P2_STAMP(2);
@@ -274,20 +305,20 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
             if (wave == 0) {
                 trailing_tile(J, J + 1, J + 1);
                 diag16_factor_invert(S, b + SB, WdJ + SB * WD_LD, info, col0, lane);
-            } else if (P2_QUIET < 0 || wave != P2_QUIET) {
-                // (wave P2_QUIET shares its SIMD with wave 0 and sits this phase out: the fp64 MFMAs of a helper
+            } else if (P2_QUIET < 0 || (wave & 3) != 0) {
+                // (waves 4, 8, .. share their SIMD with wave 0 and sit this phase out: the fp64 MFMAs of a helper
                 // there hold up every vector instruction of the pivot chain)
-                constexpr int NHE = (P2_QUIET < 0) ? NH : NH - 1;
-                const int hr = (P2_QUIET >= 0 && wave > P2_QUIET) ? wave - 2 : wave - 1;  // 0 .. NHE-1
-                int t = 0;
-                for (int K = J + 1; K < NSB; ++K)
-                    for (int I = K; I < NSB; ++I) {
-                        if (K == J + 1 && I == J + 1) continue;
-                        if ((t++ % NHE) == hr) trailing_tile(J, K, I);
-                    }
-                for (int I = J + 1; I < NSB; ++I)
-                    for (int Jp = 0; Jp <= J; ++Jp)
-                        if ((t++ % NHE) == hr) t_update(J, I, Jp);
+                constexpr int NHE = (P2_QUIET < 0) ? NH : NH - (NWV - 1) / 4;
+                const int hr = __builtin_amdgcn_readfirstlane((P2_QUIET >= 0) ? wave - 1 - (wave >> 2) : wave - 1);  // 0 .. NHE-1
+                unsigned long long lst = p2_lists<NHE>.waves[J][hr];  // this wave's tiles of the step (P2Lists)
+                while ((lst & 0xFF) != 0xFF) {
+                    const int e = (int)(lst & 0xFF);
+                    lst = (lst >> 8) | (0xFFull << 56);
+                    if (e & 64)
+                        t_update(J, (e >> 3) & 7, e & 7);
+                    else
+                        trailing_tile(J, (e >> 3) & 7, e & 7);
+                }
             }
         }
         __syncthreads();
@@ -295,7 +326,7 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
     }
     // factor -> global (lower triangle only): row r = tid & 127, columns (tid >> 7) + CG*i
     {
-        constexpr int CG = P2_THREADS / NB;
+        constexpr int CG = NT / NB;
         const int r = tid & (NB - 1), c0 = tid >> 7;
         if (r < nb) {
 #pragma unroll 8
@@ -309,7 +340,7 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
     P2_STAMP(27);
     // only the lower triangles are written: the images are zero filled once when they are allocated
     {
-        constexpr int CG = P2_THREADS / NB;
+        constexpr int CG = NT / NB;
         const int i = tid & (NB - 1), j0 = tid >> 7;
         auto W_at = [&](int r, int c) {
             return (r / SB == c / SB) ? Wd[r * WD_LD + c % SB] : S[r * LDS_LD + c];
@@ -326,7 +357,10 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
     P2_STAMP(28);
 }
 
-__global__ __launch_bounds__(P2_THREADS) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int nb,
+#ifndef P2_KTHREADS
+#define P2_KTHREADS 512  // (1024: loads and stores of the block 2.7 us faster, the steps the same; no gain in the applications)
+#endif
+__global__ __launch_bounds__(P2_KTHREADS) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int nb,
                                                         double* __restrict__ Wcm,
                                                         double* __restrict__ Wrm,
                                                         int32_t* __restrict__ info, int32_t col0,
@@ -341,7 +375,7 @@ __global__ __launch_bounds__(P2_THREADS) void potf2_inv_kernel(double* __restric
     }
     __shared__ double S[P2_S_DOUBLES];
     __shared__ double Wd[P2_WD_DOUBLES];
-    potf2_inv_body(A, lda, nb, Wcm, Wrm, info, col0, S, Wd);
+    potf2_inv_body<P2_KTHREADS>(A, lda, nb, Wcm, Wrm, info, col0, S, Wd);
 }
 
 // ---- triangular sweeps, one launch each ---------------------------------------------------------
@@ -690,7 +724,6 @@ constexpr int MID_BARRIERS = NB / BK + 1;  // barriers of one K = 128 main loop 
 __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     __shared__ __attribute__((aligned(16))) double smem[P2_S_DOUBLES + P2_WD_DOUBLES];
     static_assert(P2_S_DOUBLES + P2_WD_DOUBLES >= 8 * TILE_DOUBLES, "two GEMM halves fit the diagonal kernel's LDS");
-    static_assert(MID_THREADS == P2_THREADS, "potf2_inv_body is written for P2_THREADS threads");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave >> 2, w4 = wave & 3;
@@ -785,7 +818,7 @@ __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     }
     MID_STAMP(2);
     double* Wcm = a.winv + (int64_t)k * WBLK;
-    potf2_inv_body(a.A + i0 + i0 * a.lda, a.lda, nb, Wcm, Wcm + NB * NB, a.info, (int32_t)i0, S, smem + P2_S_DOUBLES,
+    potf2_inv_body<MID_THREADS>(a.A + i0 + i0 * a.lda, a.lda, nb, Wcm, Wcm + NB * NB, a.info, (int32_t)i0, S, smem + P2_S_DOUBLES,
                    /*tile_in_lds=*/k > 0);
     MID_STAMP(3);
 }
@@ -929,7 +962,7 @@ static int32_t factor_block(madqp_chol* s, double* A, int64_t lda, int64_t jb, i
     double* Wrm = Wcm + NB * NB;
     {
         ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(P2_THREADS), 0, ctx->stream, A + jb + jb * lda, lda,
+        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(P2_KTHREADS), 0, ctx->stream, A + jb + jb * lda, lda,
                            (int)w, Wcm, Wrm, s->d_info, (int32_t)jb, Potf2Batch{0, 0, 0, nullptr});
         LAUNCH_CHECK(ctx);
     }
@@ -1140,7 +1173,7 @@ int32_t bfactor_block(const CholBatch& c, int64_t jb, int64_t w) {
     double* Wcm = c.winv + (jb / NB) * WBLK;
     {
         ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3((unsigned)c.B), dim3(P2_THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL(potf2_inv_kernel, dim3((unsigned)c.B), dim3(P2_KTHREADS), 0, ctx->stream,
                            c.A + jb + jb * c.lda, c.lda, (int)w, Wcm, Wcm + NB * NB, c.info, (int32_t)jb,
                            Potf2Batch{c.sA, c.sW, 1, c.skip});
         LAUNCH_CHECK(ctx);
