@@ -99,18 +99,18 @@ __device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int
         for (int j = 0; j < 4; ++j) {
             const int k = k0 + j;
             double akk = readlane_f64(R[j], k);
-            if (!(akk > 0.0)) {  // not positive definite (or NaN): record the first column, go on
+            if (__builtin_expect(!(akk > 0.0), 0)) {  // not positive definite (or NaN): record the first column, go on with a unit pivot
                 if (lane == 0) atomicCAS(info, 0, col0 + b + k + 1);
                 akk = 1.0;
+                R[j] = (lo == k) ? 1.0 : R[j];
             }
             const double rd = fast_rsqrt(akk);
-            const double d = akk * rd;  // l_kk
-            const double t = R[j] * rd;
-            double lk = (lo > k) ? t : 0.0;  // exact zeros above the diagonal
-            lk = (lo == k) ? d : lk;
+            // row k scaled: column k of it is a_kk / sqrt(a_kk) = l_kk itself (the row holds a_kk there), exact zeros above
+            // the diagonal.  (The pivot steps are bound by the number of vector instructions one wave issues in order,
+            // ~48 per pivot, not by the latency of any of them: every select and masked store here is time on the chain.)
+            const double lk = (lo >= k) ? R[j] * rd : 0.0;
             l[j] = lk;
             w[j] = V[j] * rd;  // row k of W, scaled
-            if (hi == j && lo >= k) S[(b + k) * LDS_LD + b + lo] = lk;
 #pragma unroll
             for (int j2 = j + 1; j2 < 4; ++j2) {  // the later rows of the group: A[i,:] -= l_ik l_k', W[i,:] -= l_ik w_k
                 const double s = readlane_f64(lk, k0 + j2);
@@ -120,6 +120,7 @@ __device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int
         }
         const double lsel = (hi == 0) ? l[0] : (hi == 1) ? l[1] : (hi == 2) ? l[2] : l[3];
         const double wsel = (hi == 0) ? w[0] : (hi == 1) ? w[1] : (hi == 2) ? w[2] : w[3];
+        if (lo >= k0 + hi) S[(b + k0 + hi) * LDS_LD + b + lo] = lsel;  // rows k0 .. k0+3 of L, one lane group each
         A = __builtin_amdgcn_mfma_f64_16x16x4f64(-lsel, lsel, A, 0, 0, 0);
         const double aw = (lo >= k0 + 4) ? lsel : 0.0;  // rows below the group; its own rows were done above
         W = __builtin_amdgcn_mfma_f64_16x16x4f64(-aw, wsel, W, 0, 0, 0);

@@ -1,7 +1,10 @@
 set -e
+mkdir -p gpurun_out
 cp madqp_jl_amd/libmadqp_hip.so /tmp/keep.so
-for rep in 1 2; do for v in old n512 n1024; do cp madqp_jl_amd/libvar_$v.so madqp_jl_amd/libmadqp_hip.so
+for rep in 1 2; do for v in old new; do cp madqp_jl_amd/libvar_$v.so madqp_jl_amd/libmadqp_hip.so
 python bench.py --nx 5000 --ncon 2000 --steps 40 --warmup 5 --no-cpu-baseline --no-second-ncorr --no-kernel-timers --no-batch-extra 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('C2 $v', round(d['value'],1), round(d['ms_per_step'],3))"
 python tools/bench_batch.py --batch 1024 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('C3 $v', round(d['value']), [round(x,4) for x in d['all_seconds']])"
 done; done
 cp /tmp/keep.so madqp_jl_amd/libmadqp_hip.so
+python -m pytest tests -x -q -m gpu > gpurun_out/r36_tests.log 2>&1 || { tail -30 gpurun_out/r36_tests.log; exit 1; }
+tail -2 gpurun_out/r36_tests.log
