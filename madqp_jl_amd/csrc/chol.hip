@@ -48,18 +48,16 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(a) for a normal, positive pivot: hardware estimate (v_rsq_f64, ~2^-26) + two coupled
-// Goldschmidt steps in fma form -- ~10 dependent instructions on the 16-step critical chain instead of
-// the sqrt-and-divide sequence behind rsqrt().  Relative error ~1e-16.
+// 1/sqrt(a) for a normal, positive pivot: hardware estimate y (v_rsq_f64: 2^-24.2 measured) and ONE third-order step
+// y (1 + e + 3/2 e^2), e = (1 - a y^2) / 2: six instructions, four deep, on the pivot chain; max error 1.24 ulp over 4 M
+// arguments (two coupled Goldschmidt steps, the form of rounds 1-2: eight instructions, six deep, 1.90 ulp;
+// tools/scratch/rsq_probe.hip).
 __device__ __forceinline__ double fast_rsqrt(double a) {
     const double y = __builtin_amdgcn_rsq(a);
-    double g = a * y, h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    r = __builtin_fma(-h, g, 0.5);
-    h = __builtin_fma(h, r, h);
-    return h + h;
+    const double g = a * y, h = 0.5 * y;
+    const double e = __builtin_fma(-h, g, 0.5);
+    const double t = y * e, p = __builtin_fma(1.5, e, 1.0);
+    return __builtin_fma(t, p, y);
 }
 
 // One wave: Cholesky of the 16 x 16 sub-block at (b, b) of S and the inverse of its factor, in four RANK-4 steps on the
@@ -194,6 +192,36 @@ struct P2Lists {
 template <int NHE>
 __device__ __constant__ const P2Lists<NHE> p2_lists{};
 
+// LDS reads of a 16 x 16 tile product issued TOGETHER (inline asm: left to itself the compiler puts every operand pair
+// next to the MFMA that consumes it -- read, wait, MFMA, four times in a row, five LDS round trips per tile product:
+// 0.76 us per product on a helper wave where the four dependent MFMAs take 0.11).
+template <int OFF>
+__device__ __forceinline__ double p2_read(unsigned addr) {
+    double d;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+    return d;
+}
+template <int STRIDE>
+__device__ __forceinline__ void p2_read4(unsigned addr, double (&v)[4]) {
+    v[0] = p2_read<0>(addr);
+    v[1] = p2_read<STRIDE>(addr);
+    v[2] = p2_read<2 * STRIDE>(addr);
+    v[3] = p2_read<3 * STRIDE>(addr);
+}
+__device__ __forceinline__ void p2_wait(double (&a)[4], double (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 :
+                 : "memory");
+}
+__device__ __forceinline__ void p2_wait(double (&a)[4], double (&b)[4], double (&c)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                 :
+                 : "memory");
+}
+__device__ __forceinline__ unsigned p2_lds(const double* p) { return (unsigned)(uintptr_t)(lds_ptr_t)p; }
 // the whole workgroup (NT threads: 512, or 1024 in probe builds) calls this; S and Wd are its LDS work areas
 template <int NT>
 __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t lda, int nb,
@@ -228,17 +256,17 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
     // one 16 x 16 trailing tile (K, I) of step J: A_IK -= L_IJ L_KJ'
     auto trailing_tile = [&](int J, int K, int I) {
         const int b = J * SB;
-        double4_t acc;
+        double* cp = S + (SB * K + lo) * LDS_LD + SB * I + hi;
+        double c[4], av[4], bv[4];
+        p2_read4<4 * 8>(p2_lds(cp), c);
+        p2_read4<4 * LDS_LD * 8>(p2_lds(S + (b + hi) * LDS_LD + SB * I + lo), av);  // L_IJ[lo][k]
+        p2_read4<4 * LDS_LD * 8>(p2_lds(S + (b + hi) * LDS_LD + SB * K + lo), bv);  // L_KJ[lo][k]
+        p2_wait(c, av, bv);
+        double4_t acc = {c[0], c[1], c[2], c[3]};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = S[(SB * K + lo) * LDS_LD + SB * I + hi + 4 * v];
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[q], bv[q], acc, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double av = -S[(b + 4 * s + hi) * LDS_LD + SB * I + lo];  // -L_IJ[lo][k]
-            const double bv = S[(b + 4 * s + hi) * LDS_LD + SB * K + lo];   //  L_KJ[lo][k]
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) S[(SB * K + lo) * LDS_LD + SB * I + hi + 4 * v] = acc[v];
+        for (int v = 0; v < 4; ++v) cp[4 * v] = acc[v];
     };
     // W = L^-1 is built inside the same eight steps by the helper waves (wave 0's 16-step chain is the critical
     // path of a step): T_IJ' = sum_{K=J'}^{I-1} L_IK W_KJ' accumulates in the unused upper triangle (W(r, c) lives
@@ -247,19 +275,20 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
     // (row = (lane>>4) + 4v) is the B-operand layout (k = 4s + (lane>>4)), so T feeds the second product from
     // registers.  (As a separate phase after the factorisation this cost 8.4 us of the block's 58.)
     auto t_update = [&](int J, int I, int Jp) {  // T_IJ' += L_IJ W_JJ'
-        double4_t T;
+        double* tp = S + (SB * I + hi) * LDS_LD + SB * Jp + lo;
+        double c[4], av[4], bv[4];
+        p2_read4<4 * LDS_LD * 8>(p2_lds(tp), c);
+        p2_read4<4 * LDS_LD * 8>(p2_lds(S + (SB * J + hi) * LDS_LD + SB * I + lo), av);  // L_IJ[lo][k]
+        if (Jp == J)
+            p2_read4<4 * WD_LD * 8>(p2_lds(Wd + (J * SB + hi) * WD_LD + lo), bv);  // W_JJ[k][lo]
+        else
+            p2_read4<4 * LDS_LD * 8>(p2_lds(S + (SB * J + hi) * LDS_LD + SB * Jp + lo), bv);  // W_JJ'[k][lo]
+        p2_wait(c, av, bv);
+        double4_t T = {c[0], c[1], c[2], c[3]};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) T[v] = S[(SB * I + hi + 4 * v) * LDS_LD + SB * Jp + lo];
+        for (int q = 0; q < 4; ++q) T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], T, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = 4 * s + hi;
-            const double av = S[(SB * J + k) * LDS_LD + SB * I + lo];                   // L_IJ[lo][k]
-            const double bv = (Jp == J) ? Wd[(J * SB + k) * WD_LD + lo]                 // W_JJ[k][lo]
-                                        : S[(SB * J + k) * LDS_LD + SB * Jp + lo];      // W_JJ'[k][lo]
-            T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T, 0, 0, 0);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) S[(SB * I + hi + 4 * v) * LDS_LD + SB * Jp + lo] = T[v];
+        for (int v = 0; v < 4; ++v) tp[4 * v * LDS_LD] = T[v];
     };
     auto w_finish = [&](int I, int Jp) {  // W_IJ' = -W_II T_IJ'
         double4_t T, R = {0.0, 0.0, 0.0, 0.0};
