@@ -48,16 +48,21 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(a) for a normal, positive pivot: hardware estimate y (v_rsq_f64: 2^-24.2 measured) and ONE third-order step
-// y (1 + e + 3/2 e^2), e = (1 - a y^2) / 2: six instructions, four deep, on the pivot chain; max error 1.24 ulp over 4 M
-// arguments (two coupled Goldschmidt steps, the form of rounds 1-2: eight instructions, six deep, 1.90 ulp;
-// tools/scratch/rsq_probe.hip).
+// 1/sqrt(a) for a normal, positive pivot: hardware estimate (v_rsq_f64: 2^-24.2 measured) + two coupled
+// Goldschmidt steps in fma form -- eight instructions, six deep, instead of the sqrt-and-divide sequence behind rsqrt().
+// Max error 1.90 ulp over 4 M arguments (tools/scratch/rsq_probe.hip).  (One third-order step, y (1 + e + 3/2 e^2)
+// with e = (1 - a y^2) / 2, is six instructions, four deep, 1.24 ulp -- and 0.05 us per 16 pivots, which is not worth
+// moving every last bit of every factor for: the distributed path's hardest parity case then sits at 19 x instead of
+// under 16 x the distance between two CPU runs.)
 __device__ __forceinline__ double fast_rsqrt(double a) {
     const double y = __builtin_amdgcn_rsq(a);
-    const double g = a * y, h = 0.5 * y;
-    const double e = __builtin_fma(-h, g, 0.5);
-    const double t = y * e, p = __builtin_fma(1.5, e, 1.0);
-    return __builtin_fma(t, p, y);
+    double g = a * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    h = __builtin_fma(h, r, h);
+    return h + h;
 }
 
 // One wave: Cholesky of the 16 x 16 sub-block at (b, b) of S and the inverse of its factor, in four RANK-4 steps on the
