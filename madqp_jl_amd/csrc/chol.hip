@@ -723,6 +723,63 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
     sweep_diag_publish(W0, W1, vs, red, x, col0, w, tid, lane, wave);
 }
 
+// ---- panel times inverse for ONE 128-column block: L[rows, :] = C[rows, :] W'  (W = inverse of the block's factor) ----
+// The GEMM kernel does this product with a 128 x 128 tile per workgroup: at most n/128 workgroups, one round, 14 us of
+// MFMA per tile behind a staged prologue -- 23 us per launch at n = 5 000, forty times per factorisation.  Here a workgroup
+// takes 32 ROWS (four times as many workgroups; in place is safe: it reads only the rows it writes), every operand goes
+// straight from L2 to registers in the MFMA operand layout with all loads of a wave in flight at once, and the zero half
+// of the lower-triangular W is skipped: column tile jt (16 columns) meets nonzeros of W only in k < 16 (jt + 1), so a
+// wave that takes the tiles w and 7 - w runs 36 of the 64 k-steps.  D[j][i] = sum_k W(j, k) C(i, k): A-operand <- W
+// (Wcm[j + k*128]), B-operand <- C rows (C[i + k*ld]); lane l holds D[(l>>4) + 4v][l & 15] -> stores walk i.
+__global__ __launch_bounds__(256) void panel_inv_kernel(double* __restrict__ C, int64_t ld, const double* __restrict__ Wcm,
+                                                        int64_t rows) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lo = lane & 15, hi = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * 32;  // (rows up to the padded order exist: the caller's leading dimension)
+    const int jt0 = wave, jt1 = 7 - wave;          // this wave's column tiles; jt0 < jt1
+    const int ns0 = 4 * (jt0 + 1), ns1 = 4 * (jt1 + 1);  // k-steps (of 4) that meet nonzeros of W
+    const double* Cp = C + i0 + lo + (int64_t)hi * ld;
+    const double* W0 = Wcm + 16 * jt0 + lo + hi * NB;
+    const double* W1 = Wcm + 16 * jt1 + lo + hi * NB;
+    double b[32][2], a1[32], a0[16];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        if (q < ns1) {  // wave-uniform
+            b[q][0] = Cp[(int64_t)(4 * q) * ld];
+            b[q][1] = Cp[(int64_t)(4 * q) * ld + 16];
+            a1[q] = W1[4 * q * NB];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (q < ns0) a0[q] = W0[4 * q * NB];
+    double4_t d0[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, d1[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        if (q < ns1) {
+            d1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b[q][0], d1[0], 0, 0, 0);
+            d1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b[q][1], d1[1], 0, 0, 0);
+        }
+        if (q < 16 && q < ns0) {
+            d0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b[q][0], d0[0], 0, 0, 0);
+            d0[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b[q][1], d0[1], 0, 0, 0);
+        }
+    }
+    // every load of the workgroup has been consumed before the first store (all four waves read all 32 rows)
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int64_t gi = i0 + 16 * it + lo;
+        if (gi < rows) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                C[gi + (int64_t)(16 * jt0 + hi + 4 * v) * ld] = d0[it][v];
+                C[gi + (int64_t)(16 * jt1 + hi + 4 * v) * ld] = d1[it][v];
+            }
+        }
+    }
+}
+
 // ---- mid-size factorisation: right-looking, two launches per 128-column block ---------------------------------
 // Below n ~ 10 000 the left-looking schedule above is a chain of short dependent launches (per block: update with
 // split-K, its reduction, the diagonal kernel, panel times inverse -- 120 us, of which the matrix pipes are busy a
@@ -1001,6 +1058,18 @@ static int32_t factor_block(madqp_chol* s, double* A, int64_t lda, int64_t jb, i
                            (int)w, Wcm, Wrm, s->d_info, (int32_t)jb, Potf2Batch{0, 0, 0, nullptr});
         LAUNCH_CHECK(ctx);
     }
+    static const bool pp_gemm = getenv("MADQP_CHOL_PP") && atoi(getenv("MADQP_CHOL_PP")) == 0;
+    const int64_t npad_b = (n + NB - 1) / NB * NB;
+    // whole block and few rows below it (one register-heavy workgroup per CU: beyond ~24 000 rows -- 3 rounds -- the GEMM
+    // kernel's 128-row tiles, which read W once per 128 rows, are the faster form: n = 50 000 measured 1 316-1 319 against
+    // 1 311-1 315 ms per iteration with this kernel on every block)
+    if (jb + w < n && w == NB && lda >= npad_b && !pp_gemm && n - jb - NB <= 24576) {
+        ProfScope ps(ctx, MADQP_PROF_POTRF_TRSM);
+        hipLaunchKernelGGL(panel_inv_kernel, dim3((unsigned)((npad_b - jb - NB) / 32)), dim3(256), 0, ctx->stream,
+                           A + (jb + NB) + jb * lda, lda, Wcm, n - jb - NB);
+        LAUNCH_CHECK(ctx);
+        return MADQP_OK;
+    }
     if (jb + w < n) {
         // out[i,j] = sum_k C[i,k] W(j,k); in place: a single tile column, every workgroup reads
         // exactly the rows it writes and finishes reading (K = w, all stages) before its stores.
@@ -1069,7 +1138,13 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
                 LAUNCH_CHECK(ctx);
             }
             const int64_t jb = (int64_t)k * NB;
-            if (jb + NB < n) {  // L[below, jb] = C[below, jb] W_k'  (see factor_block)
+            static const bool pp_gemm = getenv("MADQP_CHOL_PP") && atoi(getenv("MADQP_CHOL_PP")) == 0;
+            if (jb + NB < n && !pp_gemm) {  // L[below, jb] = C[below, jb] W_k'
+                const int64_t below = n - jb - NB;
+                hipLaunchKernelGGL(panel_inv_kernel, dim3((unsigned)((npad_m - jb - NB) / 32)), dim3(256), 0, ctx->stream,
+                                   A + (jb + NB) + jb * lda, lda, s->winv + (int64_t)k * WBLK, below);
+                LAUNCH_CHECK(ctx);
+            } else if (jb + NB < n) {  // the same product by the GEMM kernel (see factor_block)
                 GemmArgs g{};
                 g.X = A + (jb + NB) + jb * lda;
                 g.ldx = lda;
