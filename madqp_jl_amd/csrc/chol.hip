@@ -797,6 +797,7 @@ struct MidArgs {
     int64_t lda, n;
     int32_t nblk, k;
     int32_t pack;  // tiles per workgroup (1 or 2); the diagonal tile always has its workgroup to itself
+    int32_t npair;  // pack == 2: workgroups 1 .. npair take two tiles, the ones behind them one (see chol_factor_enqueue)
     double* winv;
     int32_t* info;
 };
@@ -826,8 +827,10 @@ __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     MID_STAMP(0);
     // tile t = i'(i'+1)/2 + j' (0 <= j' <= i' < rem) is (k + i', k + j'); t = 0, the diagonal tile, is workgroup 0
     const int ntiles = rem * (rem + 1) / 2;
-    const int t = diag ? 0 : 1 + a.pack * ((int)blockIdx.x - 1) + half;
-    const bool active = diag ? (half == 0) : (t < ntiles && half < a.pack);
+    const int wg = (int)blockIdx.x - 1;  // 0-based among the workgroups of the trailing tiles
+    const bool paired = a.pack == 2 && wg < a.npair;
+    const int t = diag ? 0 : (paired || a.pack == 1 ? 1 + a.pack * wg + half : 1 + 2 * a.npair + (wg - a.npair));
+    const bool active = diag ? (half == 0) : (t < ntiles && (paired ? true : half == 0));
     int ip = 0, jp = 0;
     if (active && !diag) {
         ip = (int)((sqrtf(1.0f + 8.0f * (float)t) - 1.0f) * 0.5f);
@@ -1131,10 +1134,22 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
         for (int32_t k = 0; k < nblk; ++k) {
             {
                 const int64_t rem = nblk - k, ntiles = (k > 0) ? rem * (rem + 1) / 2 : 1;
-                const int32_t pack = (ntiles > ctx->gemm_slots / 2) ? 2 : 1;
-                const unsigned grid = (unsigned)(1 + (ntiles - 1 + pack - 1) / pack);
+                // One workgroup per CU (LDS), one or two tiles each.  Up to a round of single tiles: singles; up to a round
+                // of pairs: pairs; beyond that -- two rounds -- as few pairs as two rounds of workgroups need, FIRST in the
+                // grid, singles behind them: a CU then works off three tiles (pair + single or three singles, 44 + 22 us)
+                // instead of four (two pairs, 88 us) whenever three per CU are enough (up to 765 tiles).
+                const int64_t nt = ntiles - 1, cus = ctx->gemm_slots / 2 - 1;  // (the diagonal workgroup holds a CU)
+                int32_t pack = (nt > cus) ? 2 : 1, npair = 0;
+                unsigned grid = (unsigned)(1 + (nt + pack - 1) / pack);
+                if (pack == 2) {
+                    npair = (int32_t)((nt + 1) / 2);
+                    if (nt > 2 * cus && nt - 2 * cus <= cus) {
+                        npair = (int32_t)(nt - 2 * cus);
+                        grid = (unsigned)(1 + npair + (nt - 2 * (int64_t)npair));
+                    }
+                }
                 hipLaunchKernelGGL(chol_mid_step_kernel, dim3(grid), dim3(MID_THREADS), 0, ctx->stream,
-                                   MidArgs{A, lda, n, nblk, k, pack, s->winv, s->d_info});
+                                   MidArgs{A, lda, n, nblk, k, pack, npair, s->winv, s->d_info});
                 LAUNCH_CHECK(ctx);
             }
             const int64_t jb = (int64_t)k * NB;
