@@ -1,3 +1,3 @@
 set -e
-echo == old; ./tools/mid_probe_old 5000 | sed -n 1,6p; ./tools/mid_probe_old 5000 | sed -n 30,34p
-echo == new; ./tools/mid_probe 5000 | sed -n 1,6p; ./tools/mid_probe 5000 | sed -n 30,34p
+./tools/mid_probe 5000 | sed -n 1,5p; ./tools/mid_probe 5000 | sed -n 30,33p
+python -m pytest tests/test_gpu_dense.py -x -q 2>&1 | tail -2
