@@ -395,6 +395,16 @@ int32_t madqp_dist_matrix(madqp_dist* d, double** Kloc, int64_t* ld);
 int32_t madqp_dist_factor(madqp_dist* d, int32_t* info_host);
 int32_t madqp_dist_solve(madqp_dist* d, double* rhs);
 int32_t madqp_dist_bytes_sent(madqp_dist* d, int64_t* bytes_host);
+/* who carries the collectives, as the library sees it: out8 = (backend: 0 = one rank, 1 = RCCL, 2 = madqp_comm_ops |
+ * ranks in the world communicator (RCCL: ncclCommCount) | in my process-row communicator | in my process-column
+ * communicator | my rank in the world communicator | workgroup slots left to the collectives' kernels | internal
+ * streams (0 / 2) | 0).  bench.py puts it into every N > 1 line: a run labelled N GPUs ran its collectives on N ranks. */
+int32_t madqp_dist_comm_info(madqp_dist* d, int64_t* out8);
+/* device bytes the handle holds: out8 = (total | local matrix | stored row operands | stored column operands | solve
+ * bands | broadcast images, staging, vectors | levels of the operand staircases | 0).  The total is known before
+ * anything is allocated: madqp_dist_create returns MADQP_ERR_ALLOC with these figures in madqp_last_error when the
+ * device has less free memory than that. */
+int32_t madqp_dist_memory(madqp_dist* d, int64_t* out8);
 
 /* The condensed KKT system K = H + Sigma_x + A' Theta A (madqp_kkt_create) with K on the grid of `d` (order nx): the
  * same plugin methods -- build_kkt! / factorize! / solve! / mul! / jtprod! (src/KKT/normalkkt.jl:162-219) and the
@@ -403,7 +413,9 @@ int32_t madqp_dist_bytes_sent(madqp_dist* d, int64_t* bytes_host);
  *         diagonal tiles complete), or NULL for an LP;
  *   A_I   the columns of A of its tile ROWS:    ceil16(m) rows of length ld_ai >= ld, row k contiguous, zero padded;
  *   A_J   the columns of A of its tile COLUMNS: ceil16(m) rows of length ld_aj >= padded column count, zero padded
- * i.e. 2/(PQ) of H and K and (1/P + 1/Q) of A (C5 on 2 x 4: 52 GB per rank instead of 224 GB).  Assembly needs no
+ * i.e. 2/(PQ) of H and K and (1/P + 1/Q) of A; with the operands the factorisation stores for its lazy updates --
+ * (1/P + 1/Q) n^2/2 doubles, the factor replicated Q-fold along process rows and P-fold along columns -- C5 on 2 x 4 is
+ * 85 GB per rank (madqp_dist_memory; 224 GB on one GPU).  Assembly needs no
  * communication; iterates and scalars are replicated (madqp_state as for madqp_kkt_*), products with A, A', H are
  * summed with one all-reduce each, so every rank sees bitwise the same vectors and scalars. */
 typedef struct madqp_dkkt madqp_dkkt;

@@ -152,6 +152,8 @@ _SIGNATURES = {
     "madqp_dist_factor": [vp, pi32],
     "madqp_dist_solve": [vp, vp],
     "madqp_dist_bytes_sent": [vp, pi64],
+    "madqp_dist_comm_info": [vp, pi64],
+    "madqp_dist_memory": [vp, pi64],
     "madqp_dkkt_create": [vp, i64, i64, i64, pi64, vp, i64, vp, i64, vp, i64, C.POINTER(vp)],
     "madqp_dkkt_destroy": [vp],
     "madqp_dkkt_build": [vp, pstate],

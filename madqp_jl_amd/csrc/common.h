@@ -157,6 +157,9 @@ int32_t madqp_gemv_impl(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t col
 bool madqp_symv_lower_reads_triangle(int64_t n, const double* H, int64_t ldh);
 int32_t madqp_symv_lower(madqp_ctx* ctx, int64_t n, double alpha, const double* H, int64_t ldh, const double* x,
                          double beta, double* y, int prof_cls);
+// only the entries H[r*ldh + c] with c >= r are read, at every size (H 16-byte aligned, ldh even)
+int32_t madqp_symv_upper(madqp_ctx* ctx, int64_t n, double alpha, const double* H, int64_t ldh, const double* x,
+                         double beta, double* y, int prof_cls);
 
 // sparse.hip
 int32_t madqp_spmv_csr(madqp_ctx* ctx, int64_t rows, const int64_t* rowptr, const int64_t* col, const double* val,

@@ -21,6 +21,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // optional: madqp_dist_comm_info
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;   // optional
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -47,6 +49,8 @@ Rccl& rccl() {
     RSYM(CommInitRank, "ncclCommInitRank");
     RSYM(CommSplit, "ncclCommSplit");
     RSYM(CommDestroy, "ncclCommDestroy");
+    RSYM(CommCount, "ncclCommCount");
+    RSYM(CommUserRank, "ncclCommUserRank");
     RSYM(Broadcast, "ncclBroadcast");
     RSYM(Reduce, "ncclReduce");
     RSYM(AllReduce, "ncclAllReduce");
@@ -96,6 +100,13 @@ void* dop_alloc(Dev* dev, size_t bytes) {
     return ptr;
 }
 void dop_free(Dev*, void* ptr) { (void)hipFree(ptr); }
+// free device memory in bytes (-1: unknown); MADQP_DIST_MEM_FREE overrides the figure (tests of the refusal path)
+int64_t dop_mem_free(Dev*) {
+    if (const char* e = getenv("MADQP_DIST_MEM_FREE")) return atoll(e);
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return -1;
+    return (int64_t)fr;
+}
 int32_t dop_sync(Dev* dev) {
     HIP_TRY(dev->ctx, hipStreamSynchronize(dev->ctx->stream));
     return 0;
@@ -567,6 +578,38 @@ extern "C" int32_t madqp_dist_solve(madqp_dist* d, double* rhs) {
     return distcore::solve(d, rhs);
 }
 
+// who carries the collectives, as the LIBRARY sees it: out8 = (backend: 0 = one rank, none needed; 1 = RCCL; 2 = the
+// caller's madqp_comm_ops | ranks in the world communicator (RCCL: ncclCommCount) | ranks in my process-row communicator |
+// ranks in my process-column communicator | my rank in the world communicator (ncclCommUserRank) | workgroup slots the
+// bulk updates leave to the collectives' kernels | internal streams in use (0 / 2) | 0)
+extern "C" int32_t madqp_dist_comm_info(madqp_dist* d, int64_t* out8) {
+    if (!d || !out8) return MADQP_ERR_ARG;
+    int64_t v[8] = {0, d->world, d->Q, d->P, d->rank, d->dev->free_slots, d->dev->two_streams ? 2 : 0, 0};
+    if (d->host) {
+        v[0] = 2;
+    } else if (d->nccl[GRP_WORLD]) {
+        v[0] = 1;
+        for (int g = 0; g < 3; ++g) {
+            int c = -1;
+            if (d->nccl[g] && rccl().CommCount && rccl().CommCount((ncclComm_t)d->nccl[g], &c) == ncclSuccess) v[1 + g] = c;
+        }
+        int ur = -1;
+        if (rccl().CommUserRank && rccl().CommUserRank((ncclComm_t)d->nccl[GRP_WORLD], &ur) == ncclSuccess) v[4] = ur;
+    }
+    memcpy(out8, v, sizeof(v));
+    return MADQP_OK;
+}
+
+// device bytes this handle holds: out8 = (total | local matrix K | stored row operands XW | stored column operands YW |
+// solve bands | broadcast images, staging and vectors | levels of the operand staircases | 0)
+extern "C" int32_t madqp_dist_memory(madqp_dist* d, int64_t* out8) {
+    if (!d || !out8) return MADQP_ERR_ARG;
+    const int64_t v[8] = {d->bytes_total, d->bytes_K, 8 * d->xw_count, 8 * d->yw_count, d->bytes_band, d->bytes_stage,
+                          d->nlev, 0};
+    memcpy(out8, v, sizeof(v));
+    return MADQP_OK;
+}
+
 extern "C" int32_t madqp_dist_bytes_sent(madqp_dist* d, int64_t* bytes_host) {
     if (!d || !bytes_host) return MADQP_ERR_ARG;
     *bytes_host = d->bytes_sent;
@@ -581,10 +624,12 @@ extern "C" int32_t madqp_dist_bytes_sent(madqp_dist* d, int64_t* bytes_host) {
 //   Hloc  its tiles of H, laid out like the local K (lower tiles; diagonal tiles complete, both triangles)
 //   A_I   the columns of A that belong to its tile ROWS   (m16 x ld, row k of A contiguous, zero padded)
 //   A_J   the columns of A that belong to its tile COLUMNS (m16 x ncp)
-// -- (1/(PQ) + 1/(PQ)) of H and K, (1/P + 1/Q) of A: nothing of order n^2 or m n is replicated.  Assembly needs no
-// communication: K_loc = Hloc + A_I' (Theta A_J) is one masked MFMA GEMM over the local lower tiles.  Iterates,
-// right-hand sides and every scalar are replicated (n + m doubles); products with A, A' and H are summed over the
-// ranks with ONE all-reduce each (every lower tile of H and every column block of A has exactly one owner, the
+// -- 1/(PQ) of H and of K each and (1/P + 1/Q) of A.  (The factorisation itself keeps more: the operands of its lazy
+// updates, this rank's tile rows and tile columns of L -- (1/P + 1/Q) n^2/2 doubles as staircases, dist_core.inc; the
+// factor IS replicated Q-fold along process rows and P-fold along process columns.  madqp_dist_memory has the bytes.)
+// Assembly needs no communication: K_loc = Hloc + A_I' (Theta A_J) is one masked MFMA GEMM over the local lower tiles.
+// Iterates, right-hand sides and every scalar are replicated (n + m doubles); products with A, A' and H are summed over
+// the ranks with ONE all-reduce each (every lower tile of H and every column block of A has exactly one owner, the
 // diagonal-tile owner of that block), so all ranks see bitwise identical vectors and take identical branches.
 #define TPB 256
 #define MADQP_MAX_BLOCKS 1024
@@ -783,10 +828,14 @@ static int32_t dk_H_partial(madqp_dkkt* k, double alpha, const double* x) {
     madqp_ctx* ctx = k->ctx;
     if (!k->H || d->mloc == 0 || d->nloc == 0) return MADQP_OK;
     const int64_t nb = d->nb;
-    // one rank: the local tiles ARE the lower triangle of H (ld = ldh), x and the accumulator are whole vectors -- one
-    // pass over the triangle (gemv.hip) instead of two over every tile column (8 ms per iteration at n = 50 000)
-    if (d->world == 1 && !d->force_comm && madqp_symv_lower_reads_triangle(d->n, k->H, k->ldh))
-        return madqp_symv_lower(ctx, d->n, alpha, k->H, k->ldh, x, 1.0, k->gn, MADQP_PROF_GEMV);
+    // one rank: local order = global order, x and the accumulator are whole vectors -- one pass over the triangle
+    // (gemv.hip) instead of two over every tile column (8 ms per iteration at n = 50 000).  The contract of
+    // madqp_dkkt_create hands over the tiles I >= J of column-major H (element (i, j) at j*ldh + i; the tiles above
+    // the diagonal may hold anything -- the Julia glue's COO map never fills them): in the row-major view of the
+    // mat-vec kernels that is the side c >= r, so it is madqp_symv_upper, which reads nothing else (the
+    // first version called madqp_symv_lower here and read exactly the tiles a rank is NOT required to hold).
+    if (d->world == 1 && !d->force_comm && d->n >= 2048 && (((uintptr_t)k->H) & 15) == 0 && k->ldh % 2 == 0)
+        return madqp_symv_upper(ctx, d->n, alpha, k->H, k->ldh, x, 1.0, k->gn, MADQP_PROF_GEMV);
     {
         ProfScope ps(ctx, MADQP_PROF_VEC);
         DKL(dk_gather_kernel, d->mloc, d->mloc, nb, (int64_t)d->P, (int64_t)d->p, d->n, x, k->xr);

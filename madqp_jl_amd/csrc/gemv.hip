@@ -153,15 +153,22 @@ __global__ __launch_bounds__(256) void scale_kernel(int64_t n, double beta, doub
 // into partial[column tile][r] / partial2[row tile][c]; symv_reduce_kernel adds them in tile order: deterministic,
 // no atomics, 8 n^2/2 bytes + 0.2 GB of partials.
 constexpr int SY_TR = 256, SY_TC = 512;
-__global__ __launch_bounds__(256) void symv_lower_kernel(int64_t n, const double* __restrict__ H, int64_t ldh,
-                                                         const double* __restrict__ x, double* __restrict__ rowpart,
-                                                         double* __restrict__ colpart) {
+// UPPER = false: entries H[r*ldh + c] with c <= r are read (the lower triangle of row-major H -- equally the upper
+// triangle of a column-major matrix); UPPER = true: the entries with c >= r (the mirror image: row parts run over
+// c >= r, column parts over r < c).  A caller that holds only ONE side of the diagonal picks the side it holds: the
+// distributed KKT system stores the tiles I >= J of column-major H, element (i, j) at j*ldh + i, i.e. c >= r here.
+template <bool UPPER>
+__global__ __launch_bounds__(256) void symv_tri_kernel(int64_t n, const double* __restrict__ H, int64_t ldh,
+                                                       const double* __restrict__ x, double* __restrict__ rowpart,
+                                                       double* __restrict__ colpart) {
     __shared__ double red[4][SY_TC];
     const int64_t ct = blockIdx.x, rt = blockIdx.y;
     const int64_t r0 = rt * SY_TR, c0 = ct * SY_TC;
-    if (r0 + SY_TR - 1 < c0) return;  // wholly above the diagonal
+    if (!UPPER && r0 + SY_TR - 1 < c0) return;  // wholly above the diagonal
+    if (UPPER && c0 + SY_TC - 1 < r0) return;   // wholly below it
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const bool interior = (r0 >= c0 + SY_TC) && (r0 + SY_TR <= n) && (c0 + SY_TC <= n);  // strictly below: no masks
+    // strictly inside the triangle and the matrix: no masks
+    const bool interior = (UPPER ? (c0 >= r0 + SY_TR) : (r0 >= c0 + SY_TC)) && (r0 + SY_TR <= n) && (c0 + SY_TC <= n);
     double xc[4][2], a[4][2];
     int64_t cc[4];
 #pragma unroll
@@ -191,10 +198,12 @@ __global__ __launch_bounds__(256) void symv_lower_kernel(int64_t n, const double
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int64_t c = cc[g];
-                const double h0 = (c <= r) ? row[c] : 0.0;          // c <= r < n: inside the row
-                const double h1 = (c + 1 <= r) ? row[c + 1] : 0.0;
-                if (c < r) a[g][0] = fma(h0, xr, a[g][0]);           // strictly lower: the mirrored entry's product
-                if (c + 1 < r) a[g][1] = fma(h1, xr, a[g][1]);
+                // the held side of row r, inside the matrix (lower: c <= r < n; upper: r <= c < n)
+                const bool in0 = UPPER ? (c >= r && c < n) : (c <= r), in1 = UPPER ? (c + 1 >= r && c + 1 < n) : (c + 1 <= r);
+                const double h0 = in0 ? row[c] : 0.0;
+                const double h1 = in1 ? row[c + 1] : 0.0;
+                if (in0 && c != r) a[g][0] = fma(h0, xr, a[g][0]);  // off the diagonal: the mirrored entry's product
+                if (in1 && c + 1 != r) a[g][1] = fma(h1, xr, a[g][1]);
                 t = fma(h0, xc[g][0], t);
                 t = fma(h1, xc[g][1], t);
             }
@@ -213,17 +222,25 @@ __global__ __launch_bounds__(256) void symv_lower_kernel(int64_t n, const double
         if (c < n) colpart[rt * n + c] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
     }
 }
-// y_i = alpha (sum over the column tiles left of or on i's diagonal tile + sum over the row tiles from i's down) + beta y_i
+// y_i = alpha (row parts of the column tiles on the held side of i's row tile + column parts of the row tiles on the
+// held side of i's column tile, each in tile order) + beta y_i
+template <bool UPPER>
 __global__ __launch_bounds__(256) void symv_reduce_kernel(int64_t n, double alpha, const double* __restrict__ rowpart,
                                                           const double* __restrict__ colpart, double beta,
                                                           double* __restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t rt_i = i / SY_TR, ct_i = i / SY_TC, nrt = (n + SY_TR - 1) / SY_TR;
-    const int64_t ct_last = (rt_i * SY_TR + SY_TR - 1) / SY_TC;  // column tiles that row tile rt_i has a workgroup for
+    const int64_t rt_i = i / SY_TR, ct_i = i / SY_TC, nrt = (n + SY_TR - 1) / SY_TR, nct = (n + SY_TC - 1) / SY_TC;
     double s = 0.0;
-    for (int64_t ct = 0; ct <= ct_last; ++ct) s += rowpart[ct * n + i];
-    for (int64_t rt = 2 * ct_i; rt < nrt; ++rt) s += colpart[rt * n + i];  // rt*256 + 255 >= ct_i*512  <=>  rt >= 2 ct_i
+    if (!UPPER) {
+        const int64_t ct_last = (rt_i * SY_TR + SY_TR - 1) / SY_TC;  // column tiles that row tile rt_i has a workgroup for
+        for (int64_t ct = 0; ct <= ct_last; ++ct) s += rowpart[ct * n + i];
+        for (int64_t rt = 2 * ct_i; rt < nrt; ++rt) s += colpart[rt * n + i];  // rt*256 + 255 >= ct_i*512  <=>  rt >= 2 ct_i
+    } else {
+        for (int64_t ct = (rt_i * SY_TR) / SY_TC; ct < nct; ++ct) s += rowpart[ct * n + i];  // ct*512 + 511 >= rt_i*256
+        const int64_t rt_last = (ct_i * SY_TC + SY_TC - 1) / SY_TR;                           // rt*256 <= ct_i*512 + 511
+        for (int64_t rt = 0; rt <= rt_last && rt < nrt; ++rt) s += colpart[rt * n + i];
+    }
     y[i] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[i];
 }
 static_assert(SY_TC == 2 * SY_TR, "symv_reduce_kernel's first row tile of a column tile");
@@ -240,25 +257,44 @@ bool madqp_symv_lower_reads_triangle(int64_t n, const double* H, int64_t ldh) {
     const bool vec = (((uintptr_t)H) & 15) == 0 && (ldh % 2 == 0);
     return n >= nmin && vec;
 }
-int32_t madqp_symv_lower(madqp_ctx* ctx, int64_t n, double alpha, const double* H, int64_t ldh, const double* x,
-                         double beta, double* y, int prof_cls) {
-    ARG_TRY(ctx, ctx != nullptr && n >= 0);
-    if (n == 0) return MADQP_OK;
-    ARG_TRY(ctx, H && x && y && ldh >= n);
-    if (!madqp_symv_lower_reads_triangle(n, H, ldh)) return madqp_gemv_impl(ctx, 0, n, n, alpha, H, ldh, x, beta, y, prof_cls);
+static int32_t symv_tri(madqp_ctx* ctx, bool upper, int64_t n, double alpha, const double* H, int64_t ldh, const double* x,
+                        double beta, double* y, int prof_cls) {
     const int64_t nrt = (n + SY_TR - 1) / SY_TR, nct = (n + SY_TC - 1) / SY_TC;
     int32_t r = madqp_work_reserve(ctx, (size_t)(nrt + nct) * n * sizeof(double));
     if (r) return r;
     double* rowpart = ctx->d_work;
     double* colpart = rowpart + nct * n;
     ProfScope ps(ctx, prof_cls);
-    hipLaunchKernelGGL(symv_lower_kernel, dim3((unsigned)nct, (unsigned)nrt), dim3(256), 0, ctx->stream, n, H, ldh, x,
-                       rowpart, colpart);
-    LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(symv_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, alpha, rowpart,
-                       colpart, beta, y);
+    const dim3 grid((unsigned)nct, (unsigned)nrt), rgrid((unsigned)((n + 255) / 256));
+    if (upper) {
+        hipLaunchKernelGGL(symv_tri_kernel<true>, grid, dim3(256), 0, ctx->stream, n, H, ldh, x, rowpart, colpart);
+        LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(symv_reduce_kernel<true>, rgrid, dim3(256), 0, ctx->stream, n, alpha, rowpart, colpart, beta, y);
+    } else {
+        hipLaunchKernelGGL(symv_tri_kernel<false>, grid, dim3(256), 0, ctx->stream, n, H, ldh, x, rowpart, colpart);
+        LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(symv_reduce_kernel<false>, rgrid, dim3(256), 0, ctx->stream, n, alpha, rowpart, colpart, beta, y);
+    }
     LAUNCH_CHECK(ctx);
     return MADQP_OK;
+}
+int32_t madqp_symv_lower(madqp_ctx* ctx, int64_t n, double alpha, const double* H, int64_t ldh, const double* x,
+                         double beta, double* y, int prof_cls) {
+    ARG_TRY(ctx, ctx != nullptr && n >= 0);
+    if (n == 0) return MADQP_OK;
+    ARG_TRY(ctx, H && x && y && ldh >= n);
+    if (!madqp_symv_lower_reads_triangle(n, H, ldh)) return madqp_gemv_impl(ctx, 0, n, n, alpha, H, ldh, x, beta, y, prof_cls);
+    return symv_tri(ctx, false, n, alpha, H, ldh, x, beta, y, prof_cls);
+}
+// The same product from the OTHER side of the diagonal: only the entries H[r*ldh + c] with c >= r are read, at EVERY
+// size (the caller holds nothing else: no full-matrix path).  This is the side a column-major matrix stored by its
+// lower tiles holds -- element (i, j), i >= j, sits at j*ldh + i -- i.e. Hloc of madqp_dkkt_create on a 1 x 1 grid.
+int32_t madqp_symv_upper(madqp_ctx* ctx, int64_t n, double alpha, const double* H, int64_t ldh, const double* x,
+                         double beta, double* y, int prof_cls) {
+    ARG_TRY(ctx, ctx != nullptr && n >= 0);
+    if (n == 0) return MADQP_OK;
+    ARG_TRY(ctx, H && x && y && ldh >= n && (((uintptr_t)H) & 15) == 0 && ldh % 2 == 0);
+    return symv_tri(ctx, true, n, alpha, H, ldh, x, beta, y, prof_cls);
 }
 
 int32_t madqp_gemv_impl(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t cols, double alpha,

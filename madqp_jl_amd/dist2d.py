@@ -182,6 +182,21 @@ class DistCholesky2D:
         self.be._ck(self.be.lib.madqp_dist_bytes_sent(self._h, C.byref(b)))
         return b.value
 
+    def comm_info(self) -> dict:
+        """Who carries the collectives, as the library sees it (``madqp_dist_comm_info``)."""
+        out = (C.c_int64 * 8)()
+        self.be._ck(self.be.lib.madqp_dist_comm_info(self._h, out))
+        return dict(backend={0: "none (one rank)", 1: "rccl", 2: "host-staged callbacks (madqp_comm_ops)"}[out[0]],
+                    world_size=int(out[1]), row_comm_size=int(out[2]), col_comm_size=int(out[3]), world_rank=int(out[4]),
+                    free_slots=int(out[5]), internal_streams=int(out[6]))
+
+    def memory(self) -> dict:
+        """Device bytes of the handle by part (``madqp_dist_memory``)."""
+        out = (C.c_int64 * 8)()
+        self.be._ck(self.be.lib.madqp_dist_memory(self._h, out))
+        return dict(total_bytes=int(out[0]), matrix_bytes=int(out[1]), xw_bytes=int(out[2]), yw_bytes=int(out[3]),
+                    band_bytes=int(out[4]), staging_bytes=int(out[5]), levels=int(out[6]))
+
     def close(self):
         if self._h is not None:
             self.be.lib.madqp_dist_destroy(self._h)

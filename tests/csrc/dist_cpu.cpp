@@ -22,6 +22,12 @@ struct Dev {
 
 static void* dop_alloc(Dev*, size_t bytes) { return calloc(1, bytes); }
 static void dop_free(Dev*, void* p) { free(p); }
+// free "device" memory: unknown (-1) -- unless the test names a figure (tests/test_dist2d.py: the refusal of a problem
+// that does not fit must come from distcore::create's own sum, before anything is allocated)
+static int64_t dop_mem_free(Dev*) {
+    const char* e = getenv("MADQP_TEST_MEM_FREE");
+    return e ? atoll(e) : -1;
+}
 static int32_t dop_sync(Dev*) { return 0; }
 static int32_t dop_h2d(Dev*, void* dst, const void* src, size_t bytes) {
     memcpy(dst, src, bytes);
@@ -222,13 +228,23 @@ static int32_t dop_solve_local(Dev* dev, double* rhs) {  // one rank: forward an
     return r ? r : dop_tile_solve(dev, 1, d->K, d->ld, nullptr, rhs, d->n, nullptr);
 }
 
+static char g_last_error[256] = "";
 extern "C" {
+const char* madqp_distcpu_last_error() { return g_last_error; }
+// (total, K, XW, YW, bands, staging, levels, 0) -- madqp_dist_memory of the product
+int32_t madqp_distcpu_memory(madqp_dist* d, int64_t* out8) {
+    const int64_t v[8] = {d->bytes_total, d->bytes_K, 8 * d->xw_count, 8 * d->yw_count, d->bytes_band, d->bytes_stage,
+                          d->nlev, 0};
+    memcpy(out8, v, sizeof(v));
+    return 0;
+}
 int32_t madqp_distcpu_create(int32_t rank, int32_t world, int32_t P, int32_t Q, int64_t n, int64_t nb,
                              const madqp_comm_ops* ops, madqp_dist** out) {
     if (!out || (world > 1 && !ops)) return MADQP_ERR_ARG;
     Dev* dev = new Dev();
     int32_t r = distcore::create(dev, rank, world, P, Q, n, nb, ops, 0, out);
     if (r) {
+        if (*out) snprintf(g_last_error, sizeof(g_last_error), "%s", (*out)->err);
         distcore::destroy(*out);
         *out = nullptr;
         delete dev;

@@ -47,6 +47,9 @@ def main():
             Kloc[lj * nb:lj * nb + blk.shape[1], li * nb:li * nb + blk.shape[0]] = blk.T
 
     rec = dict(rank=rank, p=p, q=q, tiles=len(tiles), mloc=mloc, nloc=nloc)
+    mem = (C.c_int64 * 8)()
+    lib.madqp_distcpu_memory(h, mem)  # (total, K, XW, YW, bands, staging, levels, 0)
+    rec["memory"] = dict(total=mem[0], K=mem[1], xw=mem[2], yw=mem[3], levels=mem[6], ld=ld, ncp=ncp, T=T)
     load(K)
     info = C.c_int32(-1)
     rc = lib.madqp_distcpu_factor(h, C.byref(info))

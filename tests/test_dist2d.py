@@ -109,6 +109,23 @@ def test_distributed_cholesky_2d(cpuref, tmp_path, P, Q, n, nb, group, port):
     if world > 1:  # (a single rank has nobody to overlap with: one launch per trailing update, then the next panel)
         for rec in recs:
             check_lookahead_order(rec["schedule"], rec["p"], rec["q"], P, Q, T)
+    # the stored operands of the lazy updates are staircases: never more than the full rectangles ld x T nb / ncp x T nb,
+    # and with several levels close to the half of them that is ever read (60 -> ~32 GB at C5)
+    for rec in recs:
+        mm = rec["memory"]
+        full_x, full_y = 8 * mm["ld"] * mm["T"] * nb, 8 * mm["ncp"] * mm["T"] * nb
+        assert mm["xw"] <= full_x and mm["yw"] <= full_y
+        if Q == 1:
+            assert mm["xw"] == 0  # row operands read in place from the factored panels
+        if world == 1:
+            assert mm["xw"] == mm["yw"] == 0 and mm["levels"] == 1
+        elif T >= 6:
+            lev = mm["levels"]
+            assert lev >= 3
+            for got, full in ((mm["xw"], full_x), (mm["yw"], full_y)):
+                if got:  # (1/2 + 1/(2 levels)) of the rectangle + the 128-row padding of short levels
+                    assert got <= full * (0.5 + 0.5 / lev) + 8 * 128 * mm["T"] * nb + 8 * nb * nb * lev, (got, full, lev)
+        assert mm["total"] >= mm["K"] + mm["xw"] + mm["yw"]
     # solves: 2 collectives per GROUP and sweep (one reduce of the group's partial sums, one broadcast of its solution)
     G = min(group or max(1, 4096 // nb), T)
     NG = (T + G - 1) // G
@@ -120,3 +137,28 @@ def test_distributed_cholesky_2d(cpuref, tmp_path, P, Q, n, nb, group, port):
     # + the solve groups' diagonal triangles, sent once to their owners (at most G tiles + one diagonal image per step)
     assert total <= 8 * (3 * n * n // 2 + 4 * T * (nb * nb + 2 * 128 * 128 * (nb // 128)) + 64 * T * nb * max(P, Q)
                          + T * (G * nb * nb + nb * nb + 2 * 128 * 128 * (nb // 128)))
+
+
+def test_a_problem_that_does_not_fit_is_refused_before_anything_is_allocated(cpuref):
+    """create computes the per-rank byte total up front and returns MADQP_ERR_ALLOC with the figure
+    (madqp_last_error in the product) instead of failing inside the N-th allocation.  CPU build of the same
+    dist_core.inc; MADQP_TEST_MEM_FREE stands in for hipMemGetInfo."""
+    import ctypes as C
+    import textwrap
+
+    code = textwrap.dedent('''
+        import ctypes as C, json, os, sys
+        lib = C.CDLL(os.path.join(%r, "tests", "_build", "libmadqp_dist_cpuref.so"))
+        lib.madqp_distcpu_last_error.restype = C.c_char_p
+        h = C.c_void_p()
+        rc = lib.madqp_distcpu_create(0, 1, 1, 1, C.c_int64(100000), C.c_int64(1024), None, C.byref(h))
+        print(json.dumps(dict(rc=rc, handle=bool(h.value), err=lib.madqp_distcpu_last_error().decode())))
+    ''') % ROOT
+    env = dict(os.environ, MADQP_TEST_MEM_FREE=str(50 * 10**9))  # 50 GB free; n = 100 000 on one rank needs ~81 GB
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["rc"] == -3 and not rec["handle"]  # MADQP_ERR_ALLOC, nothing handed out
+    assert "GB of device memory" in rec["err"] and "50.00 GB are free" in rec["err"], rec["err"]
+    need = float(rec["err"].split(" needs ")[1].split(" GB")[0])
+    assert 80.0 < need < 81.0, rec["err"]  # the 100 096^2 local matrix alone is 80.15 GB

@@ -105,3 +105,71 @@ def test_rccl_calls_with_one_rank(tmp_path):
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     check_kkt_records([json.load(open(f"{out}.0"))])
+
+
+@pytest.mark.parametrize("n,nb,dense", [(12800, 1024, False), (2700, 512, True), (12500, 512, False)])
+def test_one_rank_hessian_products_read_only_the_tiles_a_rank_holds(hip, n, nb, dense):
+    """on a 1 x 1 grid madqp_dkkt_mul / madqp_dkkt_eval take a one-pass symmetric product over Hloc.
+    The contract of madqp_dkkt_create hands over the tiles I >= J of column-major H only ("lower tiles, diagonal tiles
+    complete") -- which is exactly what madqp_coo_map_create_tiles_cyclic, the Julia glue's compress_hessian!, fills; the
+    first version of the shortcut read the OTHER side (the tiles a rank is not required to hold: zeros from the map),
+    so every off-diagonal-tile contribution to H x was silently dropped from n_x = 12 288 up.  Here Hloc is built by the
+    COO map from a lower-triangular pattern, the tiles it does not fill are poisoned with NaN, and mul! / the model
+    evaluation must equal the dense products."""
+    import ctypes as C
+
+    import torch
+
+    from madqp_jl_amd.dist2d import DistCholesky2D, HIPDistributedCondensedKKTSystem2D
+
+    rng = np.random.default_rng(n + nb)
+    if dense:
+        G = rng.standard_normal((n, n))
+        Hs = G + G.T
+        tri = np.tril_indices(n)
+    else:  # 2 M entries all over the lower triangle + the diagonal (the host builds the map by sorting the pattern)
+        r, c = rng.integers(0, n, 2_000_000), rng.integers(0, n, 2_000_000)
+        r, c = np.concatenate([np.maximum(r, c), np.arange(n)]), np.concatenate([np.minimum(r, c), np.arange(n)])
+        key = np.unique(r * n + c)
+        tri = (key // n, key % n)
+        Hs = np.zeros((n, n))
+        Hs[tri] = rng.standard_normal(len(key))
+        Hs = Hs + np.tril(Hs, -1).T
+    x = rng.standard_normal(n)
+    grid = DistCholesky2D(hip, n, nb, (1, 1), None)
+    assert (grid.mloc, grid.nloc) == (n, n) and grid.comm_info()["backend"].startswith("none")
+    # the model's COO pattern: (part of) the lower triangle, 1-based, as MadNLP keeps it
+    hI, hJ = (tri[0] + 1).astype(np.int32), (tri[1] + 1).astype(np.int32)
+    vals = torch.as_tensor(Hs[tri], device=hip.device)
+    hmap = C.c_void_p()
+    hip._ck(hip.lib.madqp_coo_map_create_tiles_cyclic(hip.ctx, len(hI), hI.ctypes.data_as(C.c_void_p),
+                                                      hJ.ctypes.data_as(C.c_void_p), n, nb, 1, 0, 1, 0, C.byref(hmap)))
+    Hloc = torch.zeros((grid.ncp, grid.ld), dtype=torch.float64, device=hip.device)  # [local column, local row]
+    hip._ck(hip.lib.madqp_coo_map_apply(hmap, vals.data_ptr(), Hloc.data_ptr(), grid.ld))
+    hip._ck(hip.lib.madqp_coo_map_destroy(hmap))
+    hip.sync()
+    T = (n + nb - 1) // nb
+    held = torch.zeros((grid.ncp, grid.ld), dtype=torch.bool, device=hip.device)
+    for J in range(T):
+        held[J * nb:min(n, (J + 1) * nb), J * nb:n] = True  # tile column J: tile rows I >= J
+    assert torch.equal(Hloc[:n, :n][held[:n, :n]], torch.as_tensor(Hs, device=hip.device).t()[held[:n, :n]])
+    Hloc[~held] = float("nan")  # what a rank is not required to hold must never be read
+    st = hip.new_state(n, 0, np.arange(0), np.arange(0))
+    z = lambda k: torch.zeros(max(k, 1), dtype=torch.float64, device=hip.device)
+    A_I, A_J = z(16 * grid.ld).view(16, grid.ld), z(16 * grid.ncp).view(16, grid.ncp)
+    kkt = HIPDistributedCondensedKKTSystem2D(hip, st, n, [], grid, Hloc, A_I, A_J)
+    hip.fill(0.0, st.reg)
+    y0 = rng.standard_normal(n)
+    w = torch.as_tensor(y0.copy(), device=hip.device)
+    v = torch.as_tensor(x.copy(), device=hip.device)
+    kkt.mul(w, v, -0.5, 2.0)  # w = 2 w - 0.5 (H + reg) v
+    ref = 2.0 * y0 - 0.5 * (Hs @ x)
+    got = w.cpu().numpy()
+    assert not np.isnan(got).any(), "the product read a tile this rank is not required to hold"
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+    st.x.copy_(torch.as_tensor(x))
+    obj = kkt.eval_model(z(n)[:n], z(1)[:0], 0.0)
+    assert abs(obj - 0.5 * x @ Hs @ x) <= 1e-12 * abs(x @ Hs @ x)
+    assert np.max(np.abs(st.f.cpu().numpy() - Hs @ x)) <= 1e-12 * np.max(np.abs(Hs @ x))
+    kkt.close()
+    grid.close()
