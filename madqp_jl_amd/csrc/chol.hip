@@ -20,6 +20,7 @@
 // (madqp_chol_factor_batched) and its pieces for the multi-GPU panel loop (madqp_chol_factor_panel, ...).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include <vector>
 
@@ -780,6 +781,112 @@ __global__ __launch_bounds__(256) void panel_inv_kernel(double* __restrict__ C, 
     }
 }
 
+// ---- panel solve for ONE 128-column block by BLOCK SUBSTITUTION: L[rows, blk] = C[rows, blk] L_kk^-T --------------------
+// Multiplying the panel by the explicit inverse of the 128 x 128 diagonal block (panel_inv_kernel above, rounds 1-3) costs
+// cond(L_kk) in the backward error of the factorisation where LAPACK's dtrsm substitutes (tools/numerics/
+// blockchol_emul.py: on condensed LPs the device's distance from LAPACK has a tail of tens of times the distance between
+// two CPU executions, and neither a correctly rounded inverse nor a Newton-Schulz step removes it -- it is the product
+// with ANY stored 128-inverse).  Here the solve runs over the eight 16-column sub-blocks, and only the inverses of the
+// 16 x 16 DIAGONAL sub-blocks are multiplied with (statistically indistinguishable from scalar substitution in the same
+// emulation).  With Z = X' (128 x rows):
+//     Z_J = W_JJ (C'_J - sum_{I<J} L_JI Z_I),      W_JJ = (L_kk)_JJ^-1 = the diagonal 16 x 16 block of the stored inverse
+// on the MFMA unit, entirely in registers: D[m][n] += A[m][k] B[k][n] with m = row inside sub-block J, n = one of 16
+// matrix rows, k = index inside sub-block I; the accumulator layout (lane l, register v: m = (l>>4) + 4v, n = l&15) IS the
+// B-operand layout of k-step v, so a finished Z_I feeds the updates of the later sub-blocks as it stands.  A-operands
+// (tiles of L_kk, W_JJ) come straight from L2, two steps ahead.  The same 144 MFMAs per 16 rows as the inverse product
+// with its zero half skipped.  A wave owns 16 rows; in place is safe (it reads only the rows it writes, all up front).
+struct PanelBatch {  // problem blockIdx.y: pointer strides (doubles); skip[b] != 0: leave untouched
+    int64_t sC, sL, sW;
+    const int32_t* skip;
+};
+template <int J>
+__device__ __forceinline__ void ps16_load(const double* __restrict__ Lq, int64_t ldl, const double* __restrict__ Wq,
+                                          double (&aw)[4], double (&al)[7][4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) aw[s] = -Wq[16 * J + (16 * J + 4 * s) * NB];  // -W_JJ: Z_J = (-W_JJ) u_J with u = -(C' - ..)
+#pragma unroll
+    for (int d = 0; d < 7; ++d)
+        if (J + 1 + d < 8) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) al[d][s] = Lq[16 * (J + 1 + d) + (int64_t)(16 * J + 4 * s) * ldl];
+        }
+}
+template <int J>
+__device__ __forceinline__ void ps16_step(double4_t (&z)[8], const double (&aw)[4], const double (&al)[7][4]) {
+    double4_t t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) t = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[s], z[J][s], t, 0, 0, 0);
+    z[J] = t;  // Z_J
+#pragma unroll
+    for (int d = 0; d < 7; ++d)
+        if (J + 1 + d < 8) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)  // u_J2 += L_{J2,J} Z_J
+                z[J + 1 + d] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[d][s], t[s], z[J + 1 + d], 0, 0, 0);
+        }
+}
+__global__ __launch_bounds__(256) void panel_sub16_kernel(double* __restrict__ C, int64_t ld, const double* __restrict__ Lkk,
+                                                          int64_t ldl, const double* __restrict__ Wcm, int64_t rows,
+                                                          int64_t rows_read, PanelBatch bt) {
+    if (gridDim.y > 1 || bt.skip) {
+        const int64_t b = blockIdx.y;
+        if (bt.skip && bt.skip[b] != 0) return;
+        C += b * bt.sC;
+        Lkk += b * bt.sL;
+        Wcm += b * bt.sW;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lo = lane & 15, hi = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    if (i0 >= rows) return;  // (no barrier in this kernel)
+    const int64_t gi = i0 + lo;
+    const int64_t gir = gi < rows_read ? gi : rows_read - 1;  // rows that may be read: up to the padded order when it exists
+    double* Cp = C + gir + (int64_t)hi * ld;
+    const double* Lq = Lkk + lo + (int64_t)hi * ldl;
+    const double* Wq = Wcm + lo + hi * NB;
+    double aw[3][4], al[3][7][4];
+    ps16_load<0>(Lq, ldl, Wq, aw[0], al[0]);
+    ps16_load<1>(Lq, ldl, Wq, aw[1], al[1]);
+    double4_t z[8];  // u_J = -(C'_J - ..) until step J, Z_J afterwards: element (16J + hi + 4v, row gi)
+#pragma unroll
+    for (int J = 0; J < 8; ++J)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) z[J][v] = -Cp[(int64_t)(16 * J + 4 * v) * ld];
+    ps16_load<2>(Lq, ldl, Wq, aw[2], al[2]);
+    ps16_step<0>(z, aw[0], al[0]);
+    ps16_load<3>(Lq, ldl, Wq, aw[0], al[0]);
+    ps16_step<1>(z, aw[1], al[1]);
+    ps16_load<4>(Lq, ldl, Wq, aw[1], al[1]);
+    ps16_step<2>(z, aw[2], al[2]);
+    ps16_load<5>(Lq, ldl, Wq, aw[2], al[2]);
+    ps16_step<3>(z, aw[0], al[0]);
+    ps16_load<6>(Lq, ldl, Wq, aw[0], al[0]);
+    ps16_step<4>(z, aw[1], al[1]);
+    ps16_load<7>(Lq, ldl, Wq, aw[1], al[1]);
+    ps16_step<5>(z, aw[2], al[2]);
+    ps16_step<6>(z, aw[0], al[0]);
+    ps16_step<7>(z, aw[1], al[1]);
+    if (gi < rows) {
+        double* Co = C + gi + (int64_t)hi * ld;
+#pragma unroll
+        for (int J = 0; J < 8; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Co[(int64_t)(16 * J + 4 * v) * ld] = z[J][v];
+    }
+}
+// L[rows below, block] = C[..] L_kk^-T for the 128-column block whose factored diagonal block is Lkk (ldl) and whose inverse
+// image is Wcm; `rows_read`: rows of C that exist in memory (>= rows); B > 1: the same for B problems at fixed strides
+static int32_t panel_solve_sub16(madqp_ctx* ctx, double* C, int64_t ld, const double* Lkk, int64_t ldl, const double* Wcm,
+                                 int64_t rows, int64_t rows_read, int64_t B = 1, PanelBatch bt = PanelBatch{0, 0, 0, nullptr}) {
+    if (rows <= 0) return MADQP_OK;
+    ARG_TRY(ctx, B >= 1 && B <= 65535 && rows_read >= rows);
+    ProfScope ps(ctx, MADQP_PROF_POTRF_TRSM);
+    hipLaunchKernelGGL(panel_sub16_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)B), dim3(256), 0, ctx->stream, C, ld,
+                       Lkk, ldl, Wcm, rows, rows_read, bt);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
+
 // ---- mid-size factorisation: right-looking, two launches per 128-column block ---------------------------------
 // Below n ~ 10 000 the left-looking schedule above is a chain of short dependent launches (per block: update with
 // split-K, its reduction, the diagonal kernel, panel times inverse -- 120 us, of which the matrix pipes are busy a
@@ -1048,6 +1155,11 @@ static int32_t panel_update(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, i
     return madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_GEMM);
 }
 
+static bool panel_inv_mode() {
+    static const bool inv = getenv("MADQP_CHOL_PANEL") && strcmp(getenv("MADQP_CHOL_PANEL"), "inv") == 0;
+    return inv;
+}
+
 // One 128-column block whose entries already carry every update from the columns to its left:
 // factor the diagonal block (and invert it), then L[below, jb] = C[below, jb] * W_jj'.
 static int32_t factor_block(madqp_chol* s, double* A, int64_t lda, int64_t jb, int64_t w) {
@@ -1063,6 +1175,11 @@ static int32_t factor_block(madqp_chol* s, double* A, int64_t lda, int64_t jb, i
     }
     static const bool pp_gemm = getenv("MADQP_CHOL_PP") && atoi(getenv("MADQP_CHOL_PP")) == 0;
     const int64_t npad_b = (n + NB - 1) / NB * NB;
+    // the rows below the block: block substitution with the 16 x 16 diagonal inverses (panel_sub16_kernel); MADQP_CHOL_PANEL=inv
+    // brings back the products with the 128 x 128 inverse of rounds 1-3 (for the A/B numbers in DESIGN.md)
+    if (jb + w < n && w == NB && !panel_inv_mode())
+        return panel_solve_sub16(ctx, A + (jb + NB) + jb * lda, lda, A + jb + jb * lda, lda, Wcm, n - jb - NB,
+                                 lda >= npad_b ? npad_b - jb - NB : n - jb - NB);
     // whole block and few rows below it (one register-heavy workgroup per CU: beyond ~24 000 rows -- 3 rounds -- the GEMM
     // kernel's 128-row tiles, which read W once per 128 rows, are the faster form: n = 50 000 measured 1 316-1 319 against
     // 1 311-1 315 ms per iteration with this kernel on every block)
@@ -1154,7 +1271,11 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
             }
             const int64_t jb = (int64_t)k * NB;
             static const bool pp_gemm = getenv("MADQP_CHOL_PP") && atoi(getenv("MADQP_CHOL_PP")) == 0;
-            if (jb + NB < n && !pp_gemm) {  // L[below, jb] = C[below, jb] W_k'
+            if (jb + NB < n && !panel_inv_mode()) {  // L[below, jb] = C[below, jb] L_kk^-T by block substitution
+                const int32_t r = panel_solve_sub16(ctx, A + (jb + NB) + jb * lda, lda, A + jb + jb * lda, lda,
+                                                    s->winv + (int64_t)k * WBLK, n - jb - NB, npad_m - jb - NB);
+                if (r) return r;
+            } else if (jb + NB < n && !pp_gemm) {  // L[below, jb] = C[below, jb] W_k'
                 const int64_t below = n - jb - NB;
                 hipLaunchKernelGGL(panel_inv_kernel, dim3((unsigned)((npad_m - jb - NB) / 32)), dim3(256), 0, ctx->stream,
                                    A + (jb + NB) + jb * lda, lda, s->winv + (int64_t)k * WBLK, below);
@@ -1303,6 +1424,11 @@ int32_t bfactor_block(const CholBatch& c, int64_t jb, int64_t w) {
                            Potf2Batch{c.sA, c.sW, 1, c.skip});
         LAUNCH_CHECK(ctx);
     }
+    if (jb + w < c.n && w == NB && !panel_inv_mode()) {
+        const int64_t npad = (c.n + NB - 1) / NB * NB;
+        return panel_solve_sub16(ctx, c.A + (jb + NB) + jb * c.lda, c.lda, c.A + jb + jb * c.lda, c.lda, Wcm, c.n - jb - NB,
+                                 c.lda >= npad ? npad - jb - NB : c.n - jb - NB, c.B, PanelBatch{c.sA, c.sA, c.sW, c.skip});
+    }
     if (jb + w < c.n) {
         GemmArgs g{};
         g.X = c.A + (jb + w) + jb * c.lda;
@@ -1394,6 +1520,15 @@ extern "C" int32_t madqp_chol_panel_pack(madqp_chol* s, int64_t j0, int64_t w, d
                                   s->A + j0 + j0 * s->lda, s->lda * sizeof(double), rows * sizeof(double),
                                   (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
     return MADQP_OK;
+}
+
+// X (rows x 128, leading dimension ldx) <- X L^-T for ONE factored 128 x 128 block L (ldl) with the inverse image W of its
+// 16 x 16 diagonal sub-blocks (dist.hip: the leaves of a tile's panel solve); false: this build multiplies with the
+// 128 x 128 inverse instead (MADQP_CHOL_PANEL=inv) and the caller takes its GEMM form
+bool madqp_chol_panel_sub16_on() { return !panel_inv_mode(); }
+int32_t madqp_chol_panel_solve128(madqp_ctx* ctx, double* X, int64_t ldx, int64_t rows, int64_t rows_read, const double* L,
+                                  int64_t ldl, const double* Wcm) {
+    return panel_solve_sub16(ctx, X, ldx, L, ldl, Wcm, rows, rows_read);
 }
 
 // One sweep over a single order-w tile (multi-GPU solves, dist.hip): the same kernels as madqp_chol_solve.

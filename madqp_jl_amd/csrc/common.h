@@ -171,6 +171,9 @@ int32_t madqp_sparse_gram(madqp_ctx* ctx, int64_t n, const int64_t* rowptr, cons
 
 // chol.hip: one triangular sweep over an order-w tile whose factor and inverse diagonal blocks are given (dist.hip):
 // trans = 0: v <- L^-1 v, trans = 1: v <- L^-T v.  tmp: w doubles, ctl: 4 ints of device scratch.
+bool madqp_chol_panel_sub16_on();
+int32_t madqp_chol_panel_solve128(madqp_ctx* ctx, double* X, int64_t ldx, int64_t rows, int64_t rows_read, const double* L,
+                                  int64_t ldl, const double* Wcm);
 int32_t madqp_trsv_tile(madqp_ctx* ctx, int32_t trans, const double* L, int64_t ld, const double* winv, double* v,
                         int64_t w, double* tmp, int32_t* ctl);
 

@@ -258,7 +258,10 @@ int32_t dop_panel_local(Dev* dev, double* K, int64_t ld, int64_t lc, int64_t k, 
 // X (rows x w, leading dimension ldx) <- X L^-T with the inverse 128-blocks W of L's diagonal (recursive, MFMA)
 int32_t trsm_range(Dev* dev, double* X, int64_t ldx, int64_t rows, int64_t rread, const double* L, int64_t ldl,
                    const double* W, int64_t j0, int64_t wd) {
-    if (wd <= 128) {
+    if (wd == 128 && madqp_chol_panel_sub16_on())  // block substitution inside the 128-block (chol.hip: panel_sub16_kernel)
+        return madqp_chol_panel_solve128(dev->ctx, X + j0 * ldx, ldx, rows, rread, L + j0 + j0 * ldl, ldl,
+                                         W + (j0 / 128) * (2 * 128 * 128));
+    if (wd <= 128) {  // (a short last block of a tile: the product with its inverse image, zero padded to 128 x 128)
         GemmArgs g{};
         g.X = X + j0 * ldx;
         g.ldx = ldx;

@@ -80,3 +80,140 @@ def iteration_parity(r, ref, tol, what="", lp=False):
     wl, ws = worst_residual(longer["trace"][k]), worst_residual(shorter["trace"][k])
     assert ws <= tol < wl <= TIE_FACTOR * tol, (what, "not a threshold tie", r["iter"], ref["iter"], ws, wl, tol)
     return "tie"
+
+
+# ---- round 4: the noise floor from an ENSEMBLE of equally valid CPU executions ---------------------------------------
+# Two runs (LAPACK with / without a refinement step) give ONE sample of the rounding noise of a problem; on the condensed
+# LPs of the soak that single sample is, per case, anywhere between the typical distance of two valid executions and a
+# twentieth of it -- tools/numerics/blockchol_emul.py: a blocked Cholesky that SUBSTITUTES everywhere (no inverse at all)
+# sits beyond 4 x that sample on half of such LPs.  A multiplier large enough for the unlucky samples (16 in round 3) is
+# then a hand-set tolerance again.  The floor is therefore taken over several executions of the oracle that differ only in
+# how the dense solves round:
+#   "refine"      LAPACK + one step of iterative refinement per solve          (round 3's second run)
+#   "reverse"     LAPACK on the symmetrically permuted system (variables in reverse order)
+#   "blocked48"   a blocked left-looking Cholesky with substitution, blocks of 48 (numpy; another summation order)
+#   "blocked80"   the same in blocks of 80
+#   "reverse+refine"
+# floor = the largest distance of any of them from the LAPACK run, per iteration / for the solution / objective;
+# the device is allowed SENS_FACTOR times the floor where that exceeds the stated bar.
+class _ReversedLapack:
+    def __init__(self, K):
+        import scipy.linalg as sla
+
+        self.sla = sla
+        self.c = sla.cho_factor(K[::-1, ::-1].copy(), lower=True)
+
+    def solve(self, rhs):
+        return self.sla.cho_solve(self.c, rhs[::-1].copy())[::-1].copy()
+
+
+class _BlockedSubstitution:
+    def __init__(self, K, nb):
+        import numpy as np
+        import scipy.linalg as sla
+
+        n = K.shape[0]
+        self.np, self.sla = np, sla
+        L = np.tril(K).copy()
+        self.blocks = [(j, min(n, j + nb)) for j in range(0, n, nb)]
+        for j0, j1 in self.blocks:
+            if j0:
+                L[j0:, j0:j1] -= L[j0:, :j0] @ L[j0:j1, :j0].T
+            Ljj = np.linalg.cholesky(L[j0:j1, j0:j1])  # LinAlgError as scipy's cho_factor
+            L[j0:j1, j0:j1] = Ljj
+            if j1 < n:
+                L[j1:, j0:j1] = sla.solve_triangular(Ljj, L[j1:, j0:j1].T, lower=True).T
+        self.L = np.tril(L)
+
+    def solve(self, rhs):
+        L, sla = self.L, self.sla
+        y = rhs.astype(float).copy()
+        for j0, j1 in self.blocks:
+            y[j0:j1] = sla.solve_triangular(L[j0:j1, j0:j1], y[j0:j1] - L[j0:j1, :j0] @ y[:j0], lower=True)
+        for j0, j1 in reversed(self.blocks):
+            y[j0:j1] = sla.solve_triangular(L[j0:j1, j0:j1], y[j0:j1] - L[j1:, j0:j1].T @ y[j1:], lower=True, trans=1)
+        return y
+
+
+class _SlaProxy:
+    """scipy.linalg as oracle/mpc.py sees it, with the Cholesky pair swapped for another valid execution."""
+
+    def __init__(self, kind):
+        import scipy.linalg as sla
+
+        self._sla, self.kind = sla, kind
+
+    def __getattr__(self, name):
+        return getattr(self._sla, name)
+
+    def cho_factor(self, K, lower=True):
+        if self.kind == "reverse":
+            return _ReversedLapack(K)
+        return _BlockedSubstitution(K, int(self.kind[7:]))
+
+    def cho_solve(self, c, rhs):
+        return c.solve(rhs)
+
+
+ENSEMBLE = ("refine", "reverse", "blocked48", "blocked80", "reverse+refine")
+
+
+def oracle_execution(qp, kind, **opts):
+    """One run of the oracle's condensed path with its dense solves executed as `kind` (None: LAPACK, the reference)."""
+    from oracle import mpc
+
+    opts = dict(opts)
+    if kind and kind.endswith("refine"):
+        opts["refine_steps"] = 1
+        kind = kind[:-len("refine")].rstrip("+") or None
+    old = mpc.sla
+    try:
+        if kind:
+            mpc.sla = _SlaProxy(kind)
+        return mpc.solve(qp, kkt_system="condensed", **opts)
+    finally:
+        mpc.sla = old
+
+
+def rel_dist(a, b):
+    return abs(a - b) / max(1.0, abs(a), abs(b))
+
+
+def ensemble_floor(qp, ref, members=ENSEMBLE, **opts):
+    """dict(trace=[per iteration], dx, dy, obj, stopped_elsewhere): the largest distance of any member from `ref`; a
+    member that stops at another iteration says the problem is a threshold tie for the oracle itself and is only counted."""
+    import numpy as np
+
+    fl = dict(trace=[0.0] * len(ref["trace"]), dx=0.0, dy=0.0, obj=0.0, stopped_elsewhere=0, members=len(members))
+    for kind in members:
+        e = oracle_execution(qp, kind, **opts)
+        if e["iter"] != ref["iter"] or e["status"] != ref["status"]:
+            fl["stopped_elsewhere"] += 1
+            continue
+        for i, (a, b) in enumerate(zip(ref["trace"], e["trace"])):
+            fl["trace"][i] = max(fl["trace"][i], max(rel_dist(a[k], b[k]) for k in TRACE_KEYS))
+        fl["dx"] = max(fl["dx"], float(np.max(np.abs(e["solution"] - ref["solution"]), initial=0.0)))
+        fl["dy"] = max(fl["dy"], float(np.max(np.abs(e["multipliers"] - ref["multipliers"]), initial=0.0)))
+        fl["obj"] = max(fl["obj"], rel_dist(e["objective"], ref["objective"]))
+    return fl
+
+
+def ratios_to_floor(r, ref, fl):
+    """How far a result is from `ref` in units of the floor, where it exceeds the stated bar at all (else 0):
+    dict(trace, dx, obj) -- None when the iteration counts differ."""
+    import numpy as np
+
+    if r["iter"] != ref["iter"]:
+        return None
+    out = dict(trace=0.0, dx=0.0, obj=0.0)
+    for t, a, f in zip(r["trace"], ref["trace"], fl["trace"]):
+        d = max(rel_dist(t[k], a[k]) for k in TRACE_KEYS)
+        if d > stated_bar(t["mu"], a["mu"]):
+            out["trace"] = max(out["trace"], d / max(f, 1e-300))
+    dx = float(np.max(np.abs(r["solution"] - ref["solution"]), initial=0.0))
+    if dx > 1e-7:
+        out["dx"] = dx / max(fl["dx"], 1e-300)
+    do = rel_dist(r["objective"], ref["objective"])
+    if do > 1e-9:
+        out["obj"] = do / max(fl["obj"], 1e-300)
+    return out
