@@ -357,10 +357,11 @@ def pmc_traffic(nx, m):
             if d.get("config", {}).get("nx") != nx or d.get("config", {}).get("m") != m:
                 continue
             g = d["gemm_tn_f64_kernel"]
-            return (g["hbm_read_GB_corrected"] + g["hbm_write_GB"]) * 1e9 / g["dispatches"], os.path.basename(f)
+            return ((g["hbm_read_GB_corrected"] + g["hbm_write_GB"]) * 1e9 / g["dispatches"], os.path.basename(f),
+                    d.get("mfma_busy"))
         except Exception:
             continue
-    return None, None
+    return None, None, None
 
 
 def hbm_traffic(which, nx, m):
@@ -677,9 +678,9 @@ def bench_line(args, res, world, F=None):
     if shared:
         alg_flops /= world  # rank 0's share of the MFMA work (cyclic deal of the tiles)
     achieved = alg_flops / (gemm_ms * 1e-3) * 1e-12 if gemm_ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(nx, m)
+    traffic, traffic_src, mfma_busy = pmc_traffic(nx, m)
     if shared:
-        traffic, traffic_src = None, None
+        traffic, traffic_src, mfma_busy = None, None, None
     what = {"local": "one independent QP per GPU",
             "grid": "ONE QP shared by all GPUs: 2-D block-cyclic distributed assembly + Cholesky + solves over RCCL "
                     "(csrc/dist.hip)"}[mode]
@@ -728,6 +729,9 @@ def bench_line(args, res, world, F=None):
             "bound": "mfma", "kernel": "gemm_tn_f64_kernel",
             "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            # MFMA-busy counter fractions of the committed PMC passes (same command under rocprofv3 --pmc): the assembly
+            # SYRK and the Cholesky PANEL GEMM (north_star: "MFMA utilisation on the panel GEMM against chip peak")
+            "mfma_busy_counter": mfma_busy,
             "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
             "algorithmic_flops_per_launch": alg_flops / max(gemm_launches, 1),
             "split": {k: {"ms": prof[k][0], "launches": prof[k][1]} for k in prof if prof[k][1]},

@@ -69,7 +69,10 @@ __device__ __forceinline__ bool gemm_select(const KArgs& ka, GemmArgs& g) {
         g.X += k0 * g.ldx;
         g.Y += k0 * g.ldy;
         g.K = (g.K - k0 < ka.kchunk) ? (g.K - k0) : ka.kchunk;
-    } else if (ka.batch.B > 1) {  // wave-uniform pointer offsets of problem blockIdx.y
+    } else if (ka.batch.B > 1 || ka.batch.skip) {  // wave-uniform pointer offsets of problem blockIdx.y
+        // (a batch of ONE with a skip list is still a batch: round 3 ignored the list then, and the masked retry rounds of
+        // the batched engine re-assembled K over the factor of a problem that had not failed -- unnoticed while the sweeps
+        // read only the inverse images and the re-computed panels, fatal once the panel solve reads L_kk itself)
         const int64_t b = blockIdx.y;
         if (ka.batch.skip && ka.batch.skip[b] != 0) return false;
         g.X += b * ka.batch.sX;

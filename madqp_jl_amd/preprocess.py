@@ -10,11 +10,11 @@ call ``MPCSolver`` (scripts/benchmarks_cpu.jl:17-31, scripts/common.jl):
   reference takes ``Dr, Dc`` from HSL ``mc77`` (Ruiz' algorithm, infinity norm); that code is licensed
   and absent, so the published iteration is restated: agreement is in the property (unit row / column
   norms), not digit for digit;
-* :func:`standard_form` -- ``standard_form_qp`` (scripts/common.jl:109-288) line for line;
+* :func:`standard_form` -- ``standard_form_qp`` (scripts/common.jl:156-288) line for line;
 * :func:`to_device` -- hands the result to the sparse front end (``DeviceCSR``);
 * :func:`benchmark_row` -- the nine columns the scripts record (scripts/benchmarks_cpu.jl:47-55).
 
-* :func:`presolve` -- ``presolve_qp`` (scripts/common.jl:102-126) delegates to ``QuadraticModels.presolve``, an
+* :func:`presolve` -- ``presolve_qp`` (scripts/common.jl:109-126) delegates to ``QuadraticModels.presolve``, an
   un-vendored package (compat ``QuadraticModels`` in scripts/Project.toml); its documented basic reductions are
   restated here -- fixed variables, empty rows, singleton rows, unconstrained linear variables, rows made redundant
   by the variable bounds -- with the postsolve that maps a primal-dual solution back.  Same contract as the script
@@ -495,21 +495,21 @@ def ruiz_scale(qp: HostQP, **kw):
 
 # ---------------------------------------------------------------------------------------- standard form
 def standard_form(qp: HostQP) -> HostQP:
-    """``standard_form_qp`` (scripts/common.jl:109-288): slack s = A x on inequality rows, upper bounds of
+    """``standard_form_qp`` (scripts/common.jl:156-288): slack s = A x on inequality rows, upper bounds of
     range-bounded x / s moved into equality rows x + w = xu with w >= 0; equality rows and fixed variables
     kept as they are.  Variables [x; s; w], constraints [original rows; range rows]."""
     n, m = qp.nvar, qp.ncon
     lvar, uvar, lcon, ucon = qp.lvar, qp.uvar, qp.lcon, qp.ucon
-    ind_ineq = [i for i in range(m) if lcon[i] < ucon[i]]  # :140-144
+    ind_ineq = [i for i in range(m) if lcon[i] < ucon[i]]  # :163-168
     ns = len(ind_ineq)
     ind_rng, ind_fixed, xu = [], [], []
-    for i in range(n):  # :147-164
+    for i in range(n):  # :170-187
         if lvar[i] == uvar[i]:
             ind_fixed.append(i)
         elif -np.inf < lvar[i] < uvar[i] < np.inf:
             ind_rng.append(i)
             xu.append(uvar[i])
-    for k, i in enumerate(ind_ineq):  # :167-176
+    for k, i in enumerate(ind_ineq):  # :189-199
         if -np.inf < lcon[i] < ucon[i] < np.inf:
             ind_rng.append(n + k)
             xu.append(ucon[i])
@@ -517,14 +517,14 @@ def standard_form(qp: HostQP) -> HostQP:
     nvar, ncon = n + ns + nw, m + nw
     H = sp.csr_matrix((nvar, nvar))
     Hc = qp.H.tocoo()
-    H = sp.csr_matrix((Hc.data, (Hc.row, Hc.col)), shape=(nvar, nvar))  # :185
+    H = sp.csr_matrix((Hc.data, (Hc.row, Hc.col)), shape=(nvar, nvar))  # :207
     Ac = qp.A.tocoo()
     Bi, Bj, Bx = [], [], []
-    for k, i in enumerate(ind_ineq):  # slack contribution A x - s = 0, :192-197
+    for k, i in enumerate(ind_ineq):  # slack contribution A x - s = 0, :213-219
         Bi.append(i)
         Bj.append(n + k)
         Bx.append(-1.0)
-    for k, i in enumerate(ind_rng):  # x + w = xu, :199-208
+    for k, i in enumerate(ind_rng):  # x + w = xu, :220-230
         Bi += [m + k, m + k]
         Bj += [i, k + n + ns]
         Bx += [1.0, 1.0]
@@ -532,15 +532,15 @@ def standard_form(qp: HostQP) -> HostQP:
                                                        np.concatenate([Ac.col, Bj]).astype(np.int64))),
                       shape=(ncon, nvar))
     lcon_, ucon_ = np.zeros(ncon), np.zeros(ncon)
-    for i in range(m):  # :216-226
+    for i in range(m):  # :238-248
         if not lcon[i] < ucon[i]:
             lcon_[i], ucon_[i] = lcon[i], ucon[i]
-    for k in range(nw):  # :227-230
+    for k in range(nw):  # :249-252
         lcon_[m + k] = ucon_[m + k] = xu[k]
-    lvar_ = np.concatenate([lvar, lcon[ind_ineq], np.zeros(nw)])  # :232
+    lvar_ = np.concatenate([lvar, lcon[ind_ineq], np.zeros(nw)])  # :254
     uvar_ = np.concatenate([uvar, ucon[ind_ineq], np.full(nw, np.inf)])
-    uvar_[ind_rng] = np.inf  # :235
-    uvar_[ind_fixed] = uvar[ind_fixed]  # :237
+    uvar_[ind_rng] = np.inf  # :257
+    uvar_[ind_fixed] = uvar[ind_fixed]  # :259
     return HostQP(qp.c0, np.concatenate([qp.c, np.zeros(ns + nw)]), H, A, lvar_, uvar_, lcon_, ucon_,
                   x0=np.concatenate([qp.x0, np.zeros(ns + nw)]), y0=np.concatenate([qp.y0, np.zeros(nw)]),
                   name=qp.name + "-std")

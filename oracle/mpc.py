@@ -571,11 +571,14 @@ class MPCSolver:
         return mu_curr
 
     @staticmethod
-    def _argmin_first(val):
-        """mapreduce with strict '<' and init (1.0, 0): kernels.jl:243-251."""
+    def _argmin_last(val):
+        """mapreduce with the reducer ``elem1[1] < elem2[1] ? elem1 : elem2`` and init (1.0, 0), kernels.jl:243-251:
+        folded from the left the RIGHT element survives every exact tie, so the blocking index is the LAST index that
+        attains the minimum; (1.0, "nothing blocks") unless the minimum is below 1 (the index is only ever read when
+        it is, kernels.jl:351-368)."""
         if val.size == 0:
             return 1.0, -1
-        i = int(np.argmin(val))  # first minimum
+        i = val.size - 1 - int(np.argmin(val[::-1]))  # last minimum
         return (float(val[i]), i) if val[i] < 1.0 else (1.0, -1)
 
     def get_alpha_max_primal(self, tau):  # kernels.jl:242-264
@@ -583,7 +586,7 @@ class MPCSolver:
             dxl, dxu = self.dx_lr, self.dx_ur
             vl = np.where(dxl < 0, (-self.x_lr + self.xl_r) * tau / dxl, np.inf)
             vu = np.where(dxu > 0, (-self.x_ur + self.xu_r) * tau / dxu, np.inf)
-        (al, il), (au, iu) = self._argmin_first(vl), self._argmin_first(vu)
+        (al, il), (au, iu) = self._argmin_last(vl), self._argmin_last(vu)
         return al, au, il, iu
 
     def get_alpha_max_dual(self, tau):  # kernels.jl:266-288
@@ -591,7 +594,7 @@ class MPCSolver:
             dzl, dzu = self.d.zl, self.d.zu
             vl = np.where(dzl < 0, (-self.zl_r) * tau / dzl, np.inf)
             vu = np.where((dzu < 0) & (self.zu_r + dzu < 0), (-self.zu_r) * tau / dzu, np.inf)
-        (al, il), (au, iu) = self._argmin_first(vl), self._argmin_first(vu)
+        (al, il), (au, iu) = self._argmin_last(vl), self._argmin_last(vu)
         return al, au, il, iu
 
     def get_fraction_to_boundary_step(self, tau):  # kernels.jl:290-305

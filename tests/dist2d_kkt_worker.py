@@ -11,6 +11,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import madqp_jl_amd as M  # noqa: E402
 from madqp_jl_amd.dist2d import DistCholesky2D, DistributedQP, HostStagedComm  # noqa: E402
 from oracle import mpc  # noqa: E402
@@ -37,17 +38,19 @@ def solve_case(be, grid, qp, synthetic_seed=None, **opts):
     s1.close()
     okw = {k: v for k, v in opts.items() if k in ("max_ncorr",)}
     ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG, **okw)
-    # the same algorithm once more on the CPU with one refinement step per solve: what the problem's conditioning lets
-    # two accurate executions agree to (tests/parity.py)
-    ref2 = mpc.solve(qp, kkt_system="condensed", regularization=OREG, refine_steps=1, **okw)
+    # what the problem's conditioning lets valid executions of the same algorithm agree to: the ensemble noise floor of
+    # tests/parity.py (five more oracle runs), computed only when a result misses the stated bar
+    import parity
+
+    floor = None
+    if r["iter"] == ref["iter"] and (parity.exceeds_stated_bar(r, ref, multipliers=True) or
+                                     (r1["iter"] == ref["iter"] and parity.exceeds_stated_bar(r1, ref))):
+        floor = parity.ensemble_floor(qp, ref, regularization=OREG, **okw)
     keys = ("k", "alpha_p", "alpha_d", "inf_pr", "inf_du", "inf_compl", "mu")
     rec.update(status=[r["status"], ref["status"]], iters=[r["iter"], ref["iter"]],
                trace=[{k: float(t[k]) for k in keys} for t in r["trace"]],
                ref_trace=[{k: float(t[k]) for k in keys} for t in ref["trace"]],
-               ref2_trace=[{k: float(t[k]) for k in keys} for t in ref2["trace"]],
-               sens_dx=float(np.max(np.abs(ref2["solution"] - ref["solution"]))),
-               sens_dy=float(np.max(np.abs(ref2["multipliers"] - ref["multipliers"]))),
-               sens_obj=float(abs(ref2["objective"] - ref["objective"]) / max(1.0, abs(ref["objective"]))),
+               floor=floor,
                single_trace=[{k: float(t[k]) for k in keys} for t in r1["trace"]],
                dx_single=float(np.max(np.abs(r["solution"] - r1["solution"]))),
                dx=float(np.max(np.abs(r["solution"] - ref["solution"]))),

@@ -155,7 +155,7 @@ class FakeBackend:
         al, ib = [], []
         for a in v:
             if a.size and a.min() < 1.0:
-                i = int(np.argmin(a))
+                i = a.size - 1 - int(np.argmin(a[::-1]))  # the LAST minimum (src/kernels.jl:248 keeps the right element on a tie)
                 al.append(float(a[i]))
                 ib.append(i)
             else:

@@ -91,16 +91,26 @@ def main():
 
     cases = list(make_cases(a.soak_count))
     t0 = time.time()
+    cpu = {}
     with ProcessPoolExecutor(a.workers) as ex:  # (started before this process touches the GPU)
-        cpu = dict(ex.map(cpu_side, cases, chunksize=4))
+        from concurrent.futures import as_completed
+
+        futs = [ex.submit(cpu_side, c) for c in cases]  # (the five large cases come first in the list)
+        for k, f in enumerate(as_completed(futs)):
+            name, rec = f.result()
+            cpu[name] = rec
+            if k % 20 == 0:
+                print(f"[parity_table] CPU side {k + 1}/{len(cases)} ({time.time() - t0:.0f} s)", file=sys.stderr, flush=True)
     print(f"[parity_table] {len(cases)} cases, CPU side {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
     be = M.HipBackend(0)
     REG = M.FixedRegularization(1e-8, -1e-8)
     rows = []
-    for name, spec, opts in cases:
+    for kk, (name, spec, opts) in enumerate(cases):
         c = cpu[name]
         if c is None:
             continue
+        if kk % 50 == 0:
+            print(f"[parity_table] device side {kk}/{len(cases)} ({time.time() - t0:.0f} s)", file=sys.stderr, flush=True)
         qp = build(spec)
         dq = M.DeviceQP.from_numpy(be.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
         row = dict(case=name, n=int(qp.nvar), m=int(qp.ncon), lp=qp.H is None or not np.any(qp.H), iter_ref=c["ref"]["iter"],

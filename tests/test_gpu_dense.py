@@ -317,3 +317,55 @@ def test_symmetric_matvec_from_the_lower_triangle(hip, n, ld):
     assert abs(obj - 0.5 * x @ Hs @ x) <= 1e-12 * abs(x @ Hs @ x)
     assert np.max(np.abs(st.f.cpu().numpy() - Hs @ x)) <= 1e-12 * np.max(np.abs(Hs @ x))
     hip.kkt_destroy(h)
+
+
+def test_refined_sweeps_option_leaves_the_residual_of_substitution():
+    """MADQP_SWEEP_REFINE=1 (chol.hip: trsv_*_sweep_kernel<true>, off by default): the diagonal step of both sweeps as
+    z = z0 + W (v - L_rr z0) instead of the product with the stored inverse alone.  On a matrix whose diagonal blocks are
+    ill conditioned the plain product leaves a residual of cond(L_rr) eps, the refined step the residual of a
+    substitution; both must solve the system, the refined one no worse -- and the panel solve is block substitution either
+    way (MADQP_CHOL_PANEL=inv: the 128 x 128 inverse product of rounds 1-3, for comparison)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import json, sys
+        import numpy as np, torch
+        sys.path.insert(0, %r)
+        import madqp_jl_amd as M
+        be = M.HipBackend(0)
+        out = {}
+        for n in (300, 1000):
+            rng = np.random.default_rng(n)
+            Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+            K = (Qm * np.logspace(0, 11, n)) @ Qm.T        # cond 1e11, every diagonal block ill conditioned
+            K = (K + K.T) / 2
+            x = rng.standard_normal(n)
+            b = K @ x
+            ld = (n + 127) // 128 * 128
+            Kd = torch.zeros((ld, ld), dtype=torch.float64, device=be.device)
+            Kd[:n, :n] = torch.as_tensor(K, device=be.device)
+            h = be.chol_create(n)
+            assert be.chol_factor(h, Kd, ld) == 0
+            bd = torch.as_tensor(b.copy(), device=be.device)
+            be.chol_solve(h, bd)
+            xs = bd.cpu().numpy()
+            be.chol_destroy(h)
+            out[str(n)] = float(np.linalg.norm(K @ xs - b) / (np.linalg.norm(K, 2) * np.linalg.norm(xs)))
+        be.close()
+        print(json.dumps(out))
+    ''') % root
+    res = {}
+    for name, env in (("plain", {}), ("refined", {"MADQP_SWEEP_REFINE": "1"}), ("inv_panel", {"MADQP_CHOL_PANEL": "inv"})):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[name] = json.loads(p.stdout.strip().splitlines()[-1])
+    print("scaled residuals:", res)
+    for n in ("300", "1000"):
+        assert res["plain"][n] < 1e-11 and res["inv_panel"][n] < 1e-11  # (all of them solve the system)
+        assert res["refined"][n] <= 4e-16 * int(n)                         # backward stable: the residual of substitution
+        assert res["refined"][n] <= res["plain"][n] * 1.5

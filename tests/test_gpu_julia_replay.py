@@ -227,13 +227,11 @@ def test_madipm_loop_through_the_distributed_glue(rbe, name, make, ncorr, nb):
     assert type(s.kkt).__name__ == "ReplayDistributedKKTSystem"
     s.close()
     ref = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(*reg), max_ncorr=ncorr)
-    ref2 = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(*reg), max_ncorr=ncorr, refine_steps=1)
-    from parity import compare_traces_measured
+    from parity import assert_parity
 
     assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
-    compare_traces_measured(r["trace"], ref["trace"], ref2["trace"], name)
-    assert abs(r["objective"] - ref["objective"]) <= 1e-9 * max(1.0, abs(ref["objective"]))
-    assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+    # the stated bar, or 4 x the ensemble noise floor where the conditioning does not support it (tests/parity.py)
+    assert_parity(r, ref, qp, name, regularization=mpc.FixedRegularization(*reg), max_ncorr=ncorr)
 
 
 def test_every_symbol_the_glue_binds_was_replayed(rbe):

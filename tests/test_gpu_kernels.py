@@ -111,7 +111,8 @@ def test_reductions(hip, n, m):
 
 
 def test_alpha_max_ties_and_nothing_blocks(hip):
-    """Ties resolve to the smallest index; no blocking bound -> (1.0, -1) (src/kernels.jl:243-251)."""
+    """Exact ties resolve to the LAST index, as the reference's reducer `elem1[1] < elem2[1] ? elem1 : elem2` folded from the
+    left does (src/kernels.jl:248); no blocking bound -> (1.0, -1) (src/kernels.jl:243-251)."""
     n = 4000
     cpu, gpu = make_states(hip, n, 5, seed=2, identity=True)
     for st in (cpu, gpu):
@@ -127,7 +128,7 @@ def test_alpha_max_ties_and_nothing_blocks(hip):
         st.primal(st.d)[[3000, 1234, 77]] = -2.0  # three exact ties: alpha = 0.25
     a, ib = hip.get_alpha_max(gpu, 1.0)
     a_ref, ib_ref = FakeBackend().get_alpha_max(cpu, 1.0)
-    assert a == a_ref and ib == ib_ref and ib[0] == 77 and a[0] == 0.25
+    assert a == a_ref and ib == ib_ref and ib[0] == 3000 and a[0] == 0.25
 
 
 def test_nan_propagates_through_max_norms(hip):

@@ -4,9 +4,9 @@
 example DESIGN.md gave for "one iteration more than the oracle"; `seed0 = 1000` is the soak's default start.  Every
 problem runs through the Python driver, the native driver and the batched engine against the oracle with the
 acceptance rule of tests/parity.py: identical iteration counts, except threshold ties -- LPs only, counted and bounded --
-objective to 1e-9 (relative) and solution to 1e-7 (the stated bar), or 4 x the distance between two CPU
-runs of the oracle (LAPACK solves with / without one refinement step) where the problem's conditioning does not support
-the bar (round 2 had 1e-7 / 1e-5 for every problem here).
+objective to 1e-9 (relative) and solution to 1e-7 (the stated bar), or SENS_FACTOR = 4 x the noise floor
+measured over an ensemble of valid CPU executions of the oracle (tests/parity.py: ensemble_floor) where the problem's
+conditioning does not support the bar (round 2 had 1e-7 / 1e-5 for every problem here, round 3 16 x a two-run distance).
 """
 import numpy as np
 import pytest
@@ -14,7 +14,7 @@ import pytest
 import madqp_jl_amd as M
 from oracle import mpc
 from oracle import qp as Q
-from parity import SENS_FACTOR, iteration_parity
+from parity import assert_parity, iteration_parity
 
 pytestmark = pytest.mark.gpu
 REG, OREG = M.FixedRegularization(1e-8, -1e-8), mpc.FixedRegularization(1e-8, -1e-8)
@@ -34,9 +34,7 @@ def soak_cases(seed0, count, only_lp=False):
 def run_case(hip, seed, n, m, lp, drivers):
     qp = Q.random_qp(seed, n, m, lp)
     ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG)
-    ref2 = mpc.solve(qp, kkt_system="condensed", regularization=OREG, refine_steps=1)  # tests/parity.py
-    sens_obj = abs(ref2["objective"] - ref["objective"]) / max(1.0, abs(ref["objective"]))
-    sens_x = float(np.max(np.abs(ref2["solution"] - ref["solution"]), initial=0.0)) if ref2["iter"] == ref["iter"] else np.inf
+    floor = {}  # the ensemble floor of this problem, computed at most once and only if a driver misses the stated bar
     dq = M.DeviceQP.from_numpy(hip.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
     ties = []
     for name in drivers:
@@ -59,13 +57,15 @@ def run_case(hip, seed, n, m, lp, drivers):
         tie = iteration_parity(r, ref, 1e-8, what, lp=lp) == "tie"
         if tie:
             ties.append((what, r["iter"], ref["iter"]))
-        # after a tie the two points are different iterates, both of which satisfy the termination test to 1e-8
-        otol = 1e-7 if tie else max(1e-9, SENS_FACTOR * sens_obj)
-        dobj = abs(r["objective"] - ref["objective"]) / max(1.0, abs(ref["objective"]))
-        assert dobj <= otol, (what, "objective", dobj, otol)
-        if not tie and np.isfinite(sens_x):
-            dx = np.max(np.abs(r["solution"] - ref["solution"]), initial=0.0)
-            assert dx <= max(1e-7, SENS_FACTOR * sens_x), (what, "solution", dx, sens_x)
+        if tie:  # the two points are different iterates, both of which satisfy the termination test to 1e-8
+            dobj = abs(r["objective"] - ref["objective"]) / max(1.0, abs(ref["objective"]))
+            assert dobj <= 1e-7, (what, "objective after a tie", dobj)
+            continue
+        from parity import ensemble_floor, exceeds_stated_bar
+
+        if exceeds_stated_bar(r, ref, trace=False) and not floor:
+            floor.update(ensemble_floor(qp, ref, regularization=OREG))
+        assert_parity(r, ref, qp, what, trace=False, floor=floor or None, regularization=OREG)
     return ties
 
 

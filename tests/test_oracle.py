@@ -272,3 +272,28 @@ def test_seed_9195_two_hosts_is_a_threshold_tie():
     assert abs(a["objective"] - b["objective"]) <= 1e-7 * max(1.0, abs(b["objective"]))
     here = mpc.solve(Q.random_qp(9195, 186, 78, True), kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8))
     assert here["status"] == 1 and here["iter"] in (12, 13)
+
+
+def test_blocking_index_on_an_exact_tie_is_the_last_one():
+    """src/kernels.jl:243-251: `mapreduce(..., (e1, e2) -> e1[1] < e2[1] ? e1 : e2, ...; init = (1.0, 0))` is a left fold
+    that keeps the RIGHT element unless the left one is strictly smaller, so among exact ties the LAST index blocks
+    (the oracle took the first).  The fold is written out literally here; the value is min(.., 1) and
+    the index is only compared where the reference reads it (alpha < 1, src/kernels.jl:351-368)."""
+    def reference_fold(vals):
+        acc = (1.0, 0)
+        for i, v in enumerate(vals, start=1):  # 1-based, as eachindex
+            acc = acc if acc[0] < v else (v, i)
+        return acc
+
+    rng = np.random.default_rng(3)
+    cases = [[0.5, 0.25, 0.7, 0.25, 0.9], [2.0, 3.0], [1.0, 1.0], [0.3], [np.inf, 0.1, 0.1, 0.1, np.inf], [0.25] * 7]
+    cases += [list(rng.integers(1, 5, 40) / 8.0) for _ in range(20)]  # many exact ties
+    for vals in cases:
+        a, i = mpc.MPCSolver._argmin_last(np.array(vals, dtype=float))
+        fa, fi = reference_fold(vals)
+        assert a == fa
+        if fa < 1.0:
+            assert i + 1 == fi, (vals, i, fi)
+            assert vals[i] == min(vals) and all(v > vals[i] for v in vals[i + 1:])
+        else:
+            assert i == -1

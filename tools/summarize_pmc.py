@@ -34,11 +34,18 @@ def short(name):
 
 
 per = collections.defaultdict(lambda: dict(dispatches=set(), ms=0.0, counters=collections.defaultdict(float)))
-largest = {}
+# every dispatch of every pass, in dispatch order: which launches of the GEMM kernel belong to the assembly (between the
+# operand scaling and the first diagonal block of a factorisation) and which to the factorisation (after it: the wide
+# outer-panel updates, the in-panel updates)
+disp = collections.defaultdict(dict)  # kind -> dispatch id -> dict(name, ms, counters)
 for kind in ("fetch", "write", "sq", "tcc"):
     seen = set()
     for r in rows(kind):
-        k = short(r["Kernel_Name"])
+        full = r["Kernel_Name"]
+        d = disp[kind].setdefault(int(r["Dispatch_Id"]), dict(
+            name=full, ms=(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6, counters={}))
+        d["counters"][r["Counter_Name"]] = d["counters"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        k = short(full)
         if not k:
             continue
         p = per[k]
@@ -49,13 +56,24 @@ for kind in ("fetch", "write", "sq", "tcc"):
             if kind == "fetch":
                 p["dispatches"].add(r["Dispatch_Id"])
                 p["ms"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
-        if k == "gemm_tn_f64_kernel":
-            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
-            cur = largest.setdefault(kind, dict(ms=0.0, id=None, counters={}))
-            if d > cur["ms"] and r["Dispatch_Id"] != cur["id"]:
-                cur.update(ms=d, id=r["Dispatch_Id"], counters={})
-            if r["Dispatch_Id"] == cur["id"]:
-                cur["counters"][r["Counter_Name"]] = float(r["Counter_Value"])
+
+
+def largest_gemm(kind):
+    """(largest assembly dispatch, largest dispatch inside a factorisation) of the GEMM kernel in one pass"""
+    best = {"assembly": None, "panel_update": None}
+    in_fact = False
+    for i in sorted(disp[kind]):
+        d = disp[kind][i]
+        if "scale_rows_kernel" in d["name"]:
+            in_fact = False
+        elif "potf2_inv_kernel" in d["name"] or "chol_mid_step_kernel" in d["name"]:
+            in_fact = True
+        elif "gemm_tn_f64_kernel" in d["name"]:
+            which = "panel_update" if in_fact else "assembly"
+            if best[which] is None or d["ms"] > best[which]["ms"]:
+                best[which] = d
+    return best
+
 
 for k, p in per.items():
     c = dict(p["counters"])
@@ -67,16 +85,23 @@ for k, p in per.items():
     if "TCC_HIT_sum" in c:
         e["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     out[k] = e
-big = {}
-for kind, v in largest.items():
-    big[kind] = dict(ms=v["ms"], **v["counters"])
-if big:
-    rd = big.get("fetch", {}).get("FETCH_SIZE", 0) * 1024 * 2
-    wr = big.get("write", {}).get("WRITE_SIZE", 0) * 1024
-    out["largest_gemm_dispatch (the assembly SYRK)"] = dict(
-        per_pass=big, hbm_read_bytes_corrected=rd, hbm_write_bytes=wr, traffic_bytes=rd + wr,
-        mfma_busy_fraction=(big.get("sq", {}).get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0)
-        / max(big.get("sq", {}).get("ms", 1) * 1e-3 * 2.385e9, 1))
+CLOCK_HZ = 2.385e9  # measured (tools/mfma_probe.hip); SQ_VALU_MFMA_BUSY_CYCLES sums over 256 CUs x 4 SIMDs
+big = {kind: largest_gemm(kind) for kind in disp}
+for which, label in (("assembly", "largest_gemm_dispatch (the assembly SYRK)"),
+                     ("panel_update", "largest_outer_panel_update_dispatch (Cholesky panel GEMM)")):
+    pp = {kind: dict(ms=v[which]["ms"], **v[which]["counters"]) for kind, v in big.items() if v.get(which)}
+    if not pp:
+        continue
+    rd = pp.get("fetch", {}).get("FETCH_SIZE", 0) * 1024 * 2
+    wr = pp.get("write", {}).get("WRITE_SIZE", 0) * 1024
+    sq = pp.get("sq", {})
+    out[label] = dict(per_pass=pp, hbm_read_bytes_corrected=rd, hbm_write_bytes=wr, traffic_bytes=rd + wr,
+                      mfma_busy_fraction=(sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0) / max(sq.get("ms", 1) * 1e-3 * CLOCK_HZ, 1))
+out["mfma_busy"] = {
+    "assembly_syrk": out.get("largest_gemm_dispatch (the assembly SYRK)", {}).get("mfma_busy_fraction"),
+    "cholesky_panel_gemm": out.get("largest_outer_panel_update_dispatch (Cholesky panel GEMM)", {}).get("mfma_busy_fraction"),
+    "how": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x dispatch duration x 2.385 GHz), one dispatch each: the longest GEMM "
+           "launch of the assembly and the longest one inside a factorisation (a wide outer-panel update)"}
 nx = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
 # HBM-bound kernels: achieved rate = PMC bytes (read corrected + written) / duration of the same dispatches
