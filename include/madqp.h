@@ -415,7 +415,7 @@ int32_t madqp_dist_memory(madqp_dist* d, int64_t* out8);
  *   A_J   the columns of A of its tile COLUMNS: ceil16(m) rows of length ld_aj >= padded column count, zero padded
  * i.e. 2/(PQ) of H and K and (1/P + 1/Q) of A; with the operands the factorisation stores for its lazy updates --
  * (1/P + 1/Q) n^2/2 doubles, the factor replicated Q-fold along process rows and P-fold along columns -- C5 on 2 x 4 is
- * 85 GB per rank (madqp_dist_memory; 224 GB on one GPU).  Assembly needs no
+ * 84 GB per rank (madqp_dist_memory; 224 GB on one GPU).  Assembly needs no
  * communication; iterates and scalars are replicated (madqp_state as for madqp_kkt_*), products with A, A', H are
  * summed with one all-reduce each, so every rank sees bitwise the same vectors and scalars. */
 typedef struct madqp_dkkt madqp_dkkt;

@@ -315,7 +315,7 @@ end
 # tile rows (A_I) and of its tile columns (A_J), its lower tiles of H (madqp_coo_map_create_cols_cyclic /
 # _tiles_cyclic): 1/(PQ) of H and of K, (1/P + 1/Q) of A per rank.  The factorisation additionally stores the operands
 # of its lazy updates -- this rank's tile rows and tile columns of L, (1/P + 1/Q) n^2/2 doubles: the factor is replicated
-# Q-fold along process rows and P-fold along process columns (madqp_dist_memory reports the bytes; C5 on 2 x 4: 85 GB).
+# Q-fold along process rows and P-fold along process columns (madqp_dist_memory reports the bytes; C5 on 2 x 4: 84 GB).
 Base.@kwdef mutable struct DistributedConfig
     rank::Int = 0
     world::Int = 1

@@ -53,6 +53,7 @@ struct BQ {  // device view of the batch (by value in the kernel arguments); pro
     int64_t sym_len;  // doubles per problem
     double* scal;
     int32_t *status, *iters, *info, *retry_skip;
+    int32_t *retry_list, *retry_count;  // the problems of the current x100-retry round, compacted (bq_retry_kernel appends)
     madqp_mpc_options opt;
     double mu_init, bound_fac;
 };
@@ -172,7 +173,11 @@ int32_t dalloc(madqp_batch* b, T** p, int64_t count, bool zero = false) {
 }
 
 // build_kkt! + factorize! for every active problem: one assembly launch, ~2 nx/128 launches of Cholesky
-int32_t factor_all(madqp_batch* b, const int32_t* skip) {
+// retry == true: the masked x100-retry rounds -- the launches have RETRY_SLOTS problem slots in place of B problems and
+// work off the compacted list bq_retry_kernel has just written (usually empty: every workgroup leaves after one load;
+// round 3 launched B problems' worth of workgroups that each read a skip word: 1.8 % of the batch's time)
+constexpr int64_t RETRY_SLOTS = 8;
+int32_t factor_all(madqp_batch* b, const int32_t* skip, bool retry = false) {
     madqp_ctx* ctx = b->ctx;
     const BQ& q = b->q;
     if (q.dim == 0) return hipMemsetAsync(q.info, 0, q.B * sizeof(int32_t), ctx->stream) == hipSuccess
@@ -200,10 +205,14 @@ int32_t factor_all(madqp_batch* b, const int32_t* skip) {
         g.X = g.Y = q.K;
         g.Mread = g.Nread = 0;
     }
-    GemmBatch bt{q.B, q.kpad * q.npad, q.kpad * q.npad, q.ldk * q.ldk, q.nx * q.nx, q.normal ? q.m : q.n, skip};
+    static const bool compact = !(getenv("MADQP_BATCH_RETRY_COMPACT") && atoi(getenv("MADQP_BATCH_RETRY_COMPACT")) == 0);
+    const bool lst = retry && compact;
+    GemmBatch bt{lst ? RETRY_SLOTS : q.B, q.kpad * q.npad, q.kpad * q.npad, q.ldk * q.ldk, q.nx * q.nx, q.normal ? q.m : q.n,
+                 lst ? nullptr : skip, lst ? q.retry_list : nullptr, lst ? q.retry_count : nullptr};
     int32_t r = madqp_gemm_tn(ctx, g, MADQP_PROF_SYRK, nullptr, 0, &bt);
     if (r) return r;
-    return madqp_chol_factor_batched(ctx, q.K, q.ldk, q.dim, q.ldk * q.ldk, q.winv, q.nblk * WBLK, q.info, q.B, skip);
+    return madqp_chol_factor_batched(ctx, q.K, q.ldk, q.dim, q.ldk * q.ldk, q.winv, q.nblk * WBLK, q.info, q.B, skip,
+                                     RETRY_SLOTS, lst ? q.retry_list : nullptr, lst ? q.retry_count : nullptr);
 }
 }  // namespace
 
@@ -323,6 +332,8 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
     BALLOC(q.iters, B, true);
     BALLOC(q.info, B, true);
     BALLOC(q.retry_skip, B, true);
+    BALLOC(q.retry_list, B, true);
+    BALLOC(q.retry_count, 4, true);
     BALLOC(b->d_active, 1, true);
 #undef BALLOC
     if (r == MADQP_OK && ns &&
@@ -380,6 +391,7 @@ static int32_t launch_iteration(madqp_batch* b) {
     int32_t r = factor_all(b, q.status);
     if (r) return r;
     for (int trial = 1; trial < 3; ++trial) {  // src/linear_solver.jl:7: three trials in all
+        HIP_TRY(ctx, hipMemsetAsync(q.retry_count, 0, sizeof(int32_t), ctx->stream));
         {
             ProfScope ps(ctx, MADQP_PROF_VEC);
             if (b->wide)
@@ -388,7 +400,7 @@ static int32_t launch_iteration(madqp_batch* b) {
                 hipLaunchKernelGGL(wg256::bq_retry_kernel, dim3((unsigned)q.B), dim3(256), 0, ctx->stream, q);
             LAUNCH_CHECK(ctx);
         }
-        if ((r = factor_all(b, q.retry_skip))) return r;
+        if ((r = factor_all(b, q.retry_skip, true))) return r;
     }
     ProfScope ps(ctx, MADQP_PROF_VEC);
     const bool gz = q.opt.max_ncorr > 0;

@@ -159,6 +159,8 @@ __device__ unsigned long long madqp_potf2_stamps[64];  // diagnostic build only 
 struct Potf2Batch {  // problem blockIdx.x: pointer strides (doubles / ints); skip[b] != 0: leave untouched
     int64_t sA, sW, sInfo;
     const int32_t* skip;
+    const int32_t* list = nullptr;   // compacted form (GemmBatch::list): slot blockIdx.x works off list[x], list[x + grid], ..
+    const int32_t* count = nullptr;
 };
 #ifndef P2_QUIET_WAVE
 #define P2_QUIET_WAVE 4
@@ -171,7 +173,9 @@ constexpr int P2_WD_DOUBLES = NSB * SB * WD_LD;   // inverse diagonal sub-blocks
 // 8 bits, 0xFF ends the list; bit 6: 0 = trailing tile (K = bits 5..3, I = bits 2..0), 1 = inverse tile (I, J').
 // Drawn at compile time: enumerating the 34 tiles of a step in every wave (loop, modulo, three branches per tile) cost
 // more instruction issue and fetch than the products themselves -- the phase got SLOWER with more helper waves.
-template <int NHE>
+// MODE 0: trailing tiles and inverse tiles (factor + invert in one kernel); 1: trailing tiles only (factor); 2: inverse tiles
+// only (the inverse of an already factored block)
+template <int NHE, int MODE>
 struct P2Lists {
     static_assert(NHE >= 5, "at most 34 tiles per step: seven entries and the end mark per wave");
     unsigned long long waves[NB / 16][NHE];
@@ -187,16 +191,18 @@ struct P2Lists {
                 ++cnt[h];
                 ++c;
             };
-            for (int K = J + 1; K < N; ++K)
-                for (int I = K; I < N; ++I)
-                    if (!(K == J + 1 && I == J + 1)) put(K * 8 + I);
-            for (int I = J + 1; I < N; ++I)
-                for (int Jp = 0; Jp <= J; ++Jp) put(64 + I * 8 + Jp);
+            if (MODE != 2)
+                for (int K = J + 1; K < N; ++K)
+                    for (int I = K; I < N; ++I)
+                        if (!(K == J + 1 && I == J + 1)) put(K * 8 + I);
+            if (MODE != 1)
+                for (int I = J + 1; I < N; ++I)
+                    for (int Jp = 0; Jp <= J; ++Jp) put(64 + I * 8 + Jp);
         }
     }
 };
-template <int NHE>
-__device__ __constant__ const P2Lists<NHE> p2_lists{};
+template <int NHE, int MODE>
+__device__ __constant__ const P2Lists<NHE, MODE> p2_lists{};
 
 // LDS reads of a 16 x 16 tile product issued TOGETHER (inline asm: left to itself the compiler puts every operand pair
 // next to the MFMA that consumes it -- read, wait, MFMA, four times in a row, five LDS round trips per tile product:
@@ -229,7 +235,12 @@ __device__ __forceinline__ void p2_wait(double (&a)[4], double (&b)[4], double (
 }
 __device__ __forceinline__ unsigned p2_lds(const double* p) { return (unsigned)(uintptr_t)(lds_ptr_t)p; }
 // the whole workgroup (NT threads: 512, or 1024 in probe builds) calls this; S and Wd are its LDS work areas
-template <int NT>
+// MODE (round 4): 0 = factor and invert (as rounds 1-3); 1 = factor only -- L_jj and the inverses of its eight 16 x 16
+// diagonal sub-blocks, which is all the panel solve (panel_sub16_kernel) needs: the serial spine of a factorisation then
+// carries neither the inverse's tile products nor the stores of two 128 x 128 images; 2 = the inverse of an already
+// factored block from L_jj and those sub-block inverses -- every block of a factorisation in ONE launch, off the chain
+// (potf2_invert_kernel), before anything reads the images (the sweeps).
+template <int NT, int MODE = 0>
 __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t lda, int nb,
                                                double* __restrict__ Wcm, double* __restrict__ Wrm,
                                                int32_t* __restrict__ info, int32_t col0,
@@ -256,6 +267,12 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
         }
 #pragma unroll
         for (int i = 0; i < NB / CG; ++i) S[(c0 + CG * i) * LDS_LD + r] = v[i];
+    }
+    if (MODE == 2) {  // the sub-block inverses the factor-only kernel left on the diagonal of the column-major image
+        for (int e = tid; e < NSB * SB * SB; e += NT) {
+            const int J = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
+            Wd[(J * SB + rr) * WD_LD + cc] = (cc <= rr) ? Wcm[(SB * J + cc) * NB + SB * J + rr] : 0.0;
+        }
     }
     __syncthreads();
     P2_STAMP(1);
@@ -309,7 +326,7 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
         for (int v = 0; v < 4; ++v) S[(SB * I + hi + 4 * v) * LDS_LD + SB * Jp + lo] = -R[v];
     };
     constexpr int NWV = NT / 64, NH = NWV - 1;  // waves; helper waves 1..NH
-    if (wave == 0) diag16_factor_invert(S, 0, Wd, info, col0, lane);
+    if (MODE != 2 && wave == 0) diag16_factor_invert(S, 0, Wd, info, col0, lane);
     __syncthreads();
     P2_STAMP(2);
     for (int J = 0; J < NSB; ++J) {
@@ -318,9 +335,10 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
         // panel L_IJ = A_IJ * W_JJ' (I > J) and the rows W_JJ' (J' < J) of the inverse: 7 tile products
         for (int o = wave; o < NSB - 1; o += NWV) {
             if (o < J) {
-                w_finish(J, o);
+                if (MODE != 1) w_finish(J, o);
                 continue;
             }
+            if (MODE == 2) continue;  // (the panel tiles of L are final)
             const int I = o + 1;
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -339,14 +357,16 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
         // other tiles of this step and the T tiles of the inverse
         if (J + 1 < NSB) {
             if (wave == 0) {
-                trailing_tile(J, J + 1, J + 1);
-                diag16_factor_invert(S, b + SB, WdJ + SB * WD_LD, info, col0, lane);
+                if (MODE != 2) {
+                    trailing_tile(J, J + 1, J + 1);
+                    diag16_factor_invert(S, b + SB, WdJ + SB * WD_LD, info, col0, lane);
+                }
             } else if (P2_QUIET < 0 || (wave & 3) != 0) {
                 // (waves 4, 8, .. share their SIMD with wave 0 and sit this phase out: the fp64 MFMAs of a helper
                 // there hold up every vector instruction of the pivot chain)
                 constexpr int NHE = (P2_QUIET < 0) ? NH : NH - (NWV - 1) / 4;
                 const int hr = __builtin_amdgcn_readfirstlane((P2_QUIET >= 0) ? wave - 1 - (wave >> 2) : wave - 1);  // 0 .. NHE-1
-                unsigned long long lst = p2_lists<NHE>.waves[J][hr];  // this wave's tiles of the step (P2Lists)
+                unsigned long long lst = p2_lists<NHE, MODE>.waves[J][hr];  // this wave's tiles of the step (P2Lists)
                 while ((lst & 0xFF) != 0xFF) {
                     const int e = (int)(lst & 0xFF);
                     lst = (lst >> 8) | (0xFFull << 56);
@@ -361,7 +381,7 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
         P2_STAMP(4 + 3 * J);
     }
     // factor -> global (lower triangle only): row r = tid & 127, columns (tid >> 7) + CG*i
-    {
+    if (MODE != 2) {
         constexpr int CG = NT / NB;
         const int r = tid & (NB - 1), c0 = tid >> 7;
         if (r < nb) {
@@ -375,7 +395,17 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
     P2_STAMP(26);
     P2_STAMP(27);
     // only the lower triangles are written: the images are zero filled once when they are allocated
-    {
+    if (MODE == 1) {  // the eight 16 x 16 diagonal inverses, at their places in both images
+        for (int e = tid; e < NSB * SB * SB; e += NT) {
+            const int J = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
+            const int gr = SB * J + rr, gc = SB * J + cc;
+            if (cc <= rr && gr < nb) {
+                const double wv = Wd[(J * SB + rr) * WD_LD + cc];
+                Wcm[gc * NB + gr] = wv;
+                Wrm[gr * NB + gc] = wv;
+            }
+        }
+    } else {
         constexpr int CG = NT / NB;
         const int i = tid & (NB - 1), j0 = tid >> 7;
         auto W_at = [&](int r, int c) {
@@ -396,11 +426,23 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
 #ifndef P2_KTHREADS
 #define P2_KTHREADS 512  // (1024: loads and stores of the block 2.7 us faster, the steps the same; no gain in the applications)
 #endif
+template <int MODE>
 __global__ __launch_bounds__(P2_KTHREADS) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int nb,
                                                         double* __restrict__ Wcm,
                                                         double* __restrict__ Wrm,
                                                         int32_t* __restrict__ info, int32_t col0,
                                                         Potf2Batch bt) {
+    __shared__ double S[P2_S_DOUBLES];
+    __shared__ double Wd[P2_WD_DOUBLES];
+    if (bt.list) {
+        const int cnt = *bt.count;
+        for (int pb = blockIdx.x; pb < cnt; pb += gridDim.x) {
+            const int64_t b = bt.list[pb];
+            potf2_inv_body<P2_KTHREADS, MODE>(A + b * bt.sA, lda, nb, Wcm + b * bt.sW, Wrm + b * bt.sW, info + b * bt.sInfo, col0, S, Wd);
+            __syncthreads();
+        }
+        return;
+    }
     if (gridDim.x > 1 || bt.skip) {
         const int64_t b = blockIdx.x;
         if (bt.skip && bt.skip[b] != 0) return;
@@ -409,9 +451,18 @@ __global__ __launch_bounds__(P2_KTHREADS) void potf2_inv_kernel(double* __restri
         Wrm += b * bt.sW;
         info += b * bt.sInfo;
     }
+    potf2_inv_body<P2_KTHREADS, MODE>(A, lda, nb, Wcm, Wrm, info, col0, S, Wd);
+}
+// The inverse images of the diagonal blocks j0/128 .. of a factored matrix, one workgroup per block, in ONE launch: what
+// the factor-only diagonal kernel (MODE 1) leaves out of the serial spine.  A: the matrix (block b at (j0 + 128 b) (lda + 1)).
+__global__ __launch_bounds__(P2_KTHREADS) void potf2_invert_kernel(double* __restrict__ A, int64_t lda, int64_t n, int64_t j0,
+                                                                   double* __restrict__ winv) {
     __shared__ double S[P2_S_DOUBLES];
     __shared__ double Wd[P2_WD_DOUBLES];
-    potf2_inv_body<P2_KTHREADS>(A, lda, nb, Wcm, Wrm, info, col0, S, Wd);
+    const int64_t jb = j0 + (int64_t)blockIdx.x * NB;
+    const int nb = (int)((n - jb < NB) ? (n - jb) : NB);
+    double* Wcm = winv + (jb / NB) * WBLK;
+    potf2_inv_body<P2_KTHREADS, 2>(A + jb + jb * lda, lda, nb, Wcm, Wcm + NB * NB, nullptr, 0, S, Wd);
 }
 
 // ---- triangular sweeps, one launch each ---------------------------------------------------------
@@ -885,6 +936,8 @@ __global__ __launch_bounds__(256) void panel_inv_kernel(double* __restrict__ C, 
 struct PanelBatch {  // problem blockIdx.y: pointer strides (doubles); skip[b] != 0: leave untouched
     int64_t sC, sL, sW;
     const int32_t* skip;
+    const int32_t* list = nullptr;   // compacted form (GemmBatch::list)
+    const int32_t* count = nullptr;
 };
 template <int J>
 __device__ __forceinline__ void ps16_load(const double* __restrict__ Lq, int64_t ldl, const double* __restrict__ Wq,
@@ -912,16 +965,8 @@ __device__ __forceinline__ void ps16_step(double4_t (&z)[8], const double (&aw)[
                 z[J + 1 + d] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[d][s], t[s], z[J + 1 + d], 0, 0, 0);
         }
 }
-__global__ __launch_bounds__(256) void panel_sub16_kernel(double* __restrict__ C, int64_t ld, const double* __restrict__ Lkk,
-                                                          int64_t ldl, const double* __restrict__ Wcm, int64_t rows,
-                                                          int64_t rows_read, PanelBatch bt) {
-    if (gridDim.y > 1 || bt.skip) {
-        const int64_t b = blockIdx.y;
-        if (bt.skip && bt.skip[b] != 0) return;
-        C += b * bt.sC;
-        Lkk += b * bt.sL;
-        Wcm += b * bt.sW;
-    }
+__device__ __forceinline__ void panel_sub16_body(double* __restrict__ C, int64_t ld, const double* __restrict__ Lkk,
+                                                 int64_t ldl, const double* __restrict__ Wcm, int64_t rows, int64_t rows_read) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lo = lane & 15, hi = lane >> 4;
     const int64_t i0 = (int64_t)blockIdx.x * 64 + wave * 16;
@@ -961,6 +1006,27 @@ __global__ __launch_bounds__(256) void panel_sub16_kernel(double* __restrict__ C
             for (int v = 0; v < 4; ++v) Co[(int64_t)(16 * J + 4 * v) * ld] = z[J][v];
     }
 }
+
+__global__ __launch_bounds__(256) void panel_sub16_kernel(double* __restrict__ C, int64_t ld, const double* __restrict__ Lkk,
+                                                          int64_t ldl, const double* __restrict__ Wcm, int64_t rows,
+                                                          int64_t rows_read, PanelBatch bt) {
+    if (bt.list) {  // compacted batch: the problems of slot blockIdx.y, one after the other (no barrier in the body)
+        const int cnt = *bt.count;
+        for (int pb = blockIdx.y; pb < cnt; pb += gridDim.y) {
+            const int64_t b = bt.list[pb];
+            panel_sub16_body(C + b * bt.sC, ld, Lkk + b * bt.sL, ldl, Wcm + b * bt.sW, rows, rows_read);
+        }
+        return;
+    }
+    if (gridDim.y > 1 || bt.skip) {
+        const int64_t b = blockIdx.y;
+        if (bt.skip && bt.skip[b] != 0) return;
+        C += b * bt.sC;
+        Lkk += b * bt.sL;
+        Wcm += b * bt.sW;
+    }
+    panel_sub16_body(C, ld, Lkk, ldl, Wcm, rows, rows_read);
+}
 // L[rows below, block] = C[..] L_kk^-T for the 128-column block whose factored diagonal block is Lkk (ldl) and whose inverse
 // image is Wcm; `rows_read`: rows of C that exist in memory (>= rows); B > 1: the same for B problems at fixed strides
 static int32_t panel_solve_sub16(madqp_ctx* ctx, double* C, int64_t ld, const double* Lkk, int64_t ldl, const double* Wcm,
@@ -992,6 +1058,7 @@ struct MidArgs {
     int32_t nblk, k;
     int32_t pack;  // tiles per workgroup (1 or 2); the diagonal tile always has its workgroup to itself
     int32_t npair;  // pack == 2: workgroups 1 .. npair take two tiles, the ones behind them one (see chol_factor_enqueue)
+    int32_t lite;   // the diagonal workgroup factors only (MODE 1); the inverse images follow in one launch at the end
     double* winv;
     int32_t* info;
 };
@@ -1107,8 +1174,12 @@ __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     }
     MID_STAMP(2);
     double* Wcm = a.winv + (int64_t)k * WBLK;
-    potf2_inv_body<MID_THREADS>(a.A + i0 + i0 * a.lda, a.lda, nb, Wcm, Wcm + NB * NB, a.info, (int32_t)i0, S, smem + P2_S_DOUBLES,
-                   /*tile_in_lds=*/k > 0);
+    if (a.lite)
+        potf2_inv_body<MID_THREADS, 1>(a.A + i0 + i0 * a.lda, a.lda, nb, Wcm, Wcm + NB * NB, a.info, (int32_t)i0, S,
+                                       smem + P2_S_DOUBLES, /*tile_in_lds=*/k > 0);
+    else
+        potf2_inv_body<MID_THREADS, 0>(a.A + i0 + i0 * a.lda, a.lda, nb, Wcm, Wcm + NB * NB, a.info, (int32_t)i0, S,
+                                       smem + P2_S_DOUBLES, /*tile_in_lds=*/k > 0);
     MID_STAMP(3);
 }
 
@@ -1242,6 +1313,22 @@ static int32_t panel_update(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, i
     return madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_GEMM);
 }
 
+// factor-only diagonal kernels + one inversion launch per factorisation (round 4); MADQP_CHOL_LITE=0: factor and invert in
+// the diagonal kernel as before.  Needs the block-substitution panel solve (the product with the 128-inverse reads the image).
+static bool panel_inv_mode();
+static bool chol_lite() {
+    static const bool on = !(getenv("MADQP_CHOL_LITE") && atoi(getenv("MADQP_CHOL_LITE")) == 0);
+    return on && !panel_inv_mode();
+}
+static int32_t invert_blocks(madqp_chol* s, double* A, int64_t lda, int64_t j0, int64_t w) {
+    if (w <= 0 || !chol_lite()) return MADQP_OK;
+    madqp_ctx* ctx = s->ctx;
+    ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
+    hipLaunchKernelGGL(potf2_invert_kernel, dim3((unsigned)((w + NB - 1) / NB)), dim3(P2_KTHREADS), 0, ctx->stream, A, lda, s->n, j0,
+                       s->winv);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
 static bool sweep_refine() {  // the refined diagonal step of both sweeps (trsv_*_sweep_kernel<true>); off by default
     static const bool on = getenv("MADQP_SWEEP_REFINE") && atoi(getenv("MADQP_SWEEP_REFINE")) != 0;
     return on;
@@ -1260,8 +1347,12 @@ static int32_t factor_block(madqp_chol* s, double* A, int64_t lda, int64_t jb, i
     double* Wrm = Wcm + NB * NB;
     {
         ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(P2_KTHREADS), 0, ctx->stream, A + jb + jb * lda, lda,
-                           (int)w, Wcm, Wrm, s->d_info, (int32_t)jb, Potf2Batch{0, 0, 0, nullptr});
+        if (chol_lite())
+            hipLaunchKernelGGL(potf2_inv_kernel<1>, dim3(1), dim3(P2_KTHREADS), 0, ctx->stream, A + jb + jb * lda, lda,
+                               (int)w, Wcm, Wrm, s->d_info, (int32_t)jb, Potf2Batch{0, 0, 0, nullptr});
+        else
+            hipLaunchKernelGGL(potf2_inv_kernel<0>, dim3(1), dim3(P2_KTHREADS), 0, ctx->stream, A + jb + jb * lda, lda,
+                               (int)w, Wcm, Wrm, s->d_info, (int32_t)jb, Potf2Batch{0, 0, 0, nullptr});
         LAUNCH_CHECK(ctx);
     }
     static const bool pp_gemm = getenv("MADQP_CHOL_PP") && atoi(getenv("MADQP_CHOL_PP")) == 0;
@@ -1357,7 +1448,7 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
                     }
                 }
                 hipLaunchKernelGGL(chol_mid_step_kernel, dim3(grid), dim3(MID_THREADS), 0, ctx->stream,
-                                   MidArgs{A, lda, n, nblk, k, pack, npair, s->winv, s->d_info});
+                                   MidArgs{A, lda, n, nblk, k, pack, npair, chol_lite() ? 1 : 0, s->winv, s->d_info});
                 LAUNCH_CHECK(ctx);
             }
             const int64_t jb = (int64_t)k * NB;
@@ -1390,7 +1481,7 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
                 if (r) return r;
             }
         }
-        return MADQP_OK;
+        return invert_blocks(s, A, lda, 0, n);  // the inverse images of all blocks, one launch (factor-only diagonal kernels)
     }
     // Quasi-definite mode (npos < n): A = [P, .; B, -Q] with P, Q positive definite and Q's block STORED AS +Q.
     // A = L diag(I, -I) L' with L = [L11, 0; W, L22], W = B L11^-T, L22 L22' = Q + W W': the same left-looking
@@ -1412,7 +1503,7 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
         r = factor_range(s, A, lda, J0, W);
         if (r) return r;
     }
-    return MADQP_OK;
+    return invert_blocks(s, A, lda, 0, n);
 }
 
 extern "C" int32_t madqp_chol_factor(madqp_chol* s, double* A, int64_t lda, int32_t* info_host) {
@@ -1480,6 +1571,8 @@ struct CholBatch {
     int32_t* info;
     int64_t B;
     const int32_t* skip;
+    const int32_t* list;   // compacted form (GemmBatch::list): B = the number of slots
+    const int32_t* count;
 };
 int32_t bfactor_update(const CholBatch& c, int64_t row0, int64_t k0, int64_t width) {
     GemmArgs g{};
@@ -1502,7 +1595,7 @@ int32_t bfactor_update(const CholBatch& c, int64_t row0, int64_t k0, int64_t wid
         g.Nread = std::min<int64_t>(npad - row0, (width + NB - 1) / NB * NB);
     }
     g.lower_only = 1;
-    GemmBatch bt{c.B, c.sA, c.sA, c.sA, c.sA, 0, c.skip};
+    GemmBatch bt{c.B, c.sA, c.sA, c.sA, c.sA, 0, c.skip, c.list, c.count};
     return madqp_gemm_tn(c.ctx, g, MADQP_PROF_POTRF_GEMM, nullptr, 0, &bt);
 }
 int32_t bfactor_block(const CholBatch& c, int64_t jb, int64_t w) {
@@ -1510,15 +1603,15 @@ int32_t bfactor_block(const CholBatch& c, int64_t jb, int64_t w) {
     double* Wcm = c.winv + (jb / NB) * WBLK;
     {
         ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3((unsigned)c.B), dim3(P2_KTHREADS), 0, ctx->stream,
+        hipLaunchKernelGGL(potf2_inv_kernel<0>, dim3((unsigned)c.B), dim3(P2_KTHREADS), 0, ctx->stream,
                            c.A + jb + jb * c.lda, c.lda, (int)w, Wcm, Wcm + NB * NB, c.info, (int32_t)jb,
-                           Potf2Batch{c.sA, c.sW, 1, c.skip});
+                           Potf2Batch{c.sA, c.sW, 1, c.skip, c.list, c.count});
         LAUNCH_CHECK(ctx);
     }
     if (jb + w < c.n && w == NB && !panel_inv_mode()) {
         const int64_t npad = (c.n + NB - 1) / NB * NB;
         return panel_solve_sub16(ctx, c.A + (jb + NB) + jb * c.lda, c.lda, c.A + jb + jb * c.lda, c.lda, Wcm, c.n - jb - NB,
-                                 c.lda >= npad ? npad - jb - NB : c.n - jb - NB, c.B, PanelBatch{c.sA, c.sA, c.sW, c.skip});
+                                 c.lda >= npad ? npad - jb - NB : c.n - jb - NB, c.B, PanelBatch{c.sA, c.sA, c.sW, c.skip, c.list, c.count});
     }
     if (jb + w < c.n) {
         GemmArgs g{};
@@ -1536,7 +1629,7 @@ int32_t bfactor_block(const CholBatch& c, int64_t jb, int64_t w) {
         const int64_t npad = (c.n + NB - 1) / NB * NB;
         if (c.lda >= npad) g.Mread = npad - jb - w;
         g.Nread = NB;
-        GemmBatch bt{c.B, c.sA, c.sW, c.sA, 0, 0, c.skip};
+        GemmBatch bt{c.B, c.sA, c.sW, c.sA, 0, 0, c.skip, c.list, c.count};
         return madqp_gemm_tn(ctx, g, MADQP_PROF_POTRF_TRSM, nullptr, 0, &bt);
     }
     return MADQP_OK;
@@ -1553,11 +1646,12 @@ int32_t bfactor_range(const CholBatch& c, int64_t j0, int64_t w) {
 
 // internal (batch.hip): asynchronous; info[b] = 0 or the first failing column of problem b (1-based)
 int32_t madqp_chol_factor_batched(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t sA, double* winv,
-                                  int64_t sW, int32_t* info, int64_t B, const int32_t* skip) {
-    ARG_TRY(ctx, A && winv && info && lda >= n && B >= 1);
+                                  int64_t sW, int32_t* info, int64_t B, const int32_t* skip, int64_t slots,
+                                  const int32_t* list, const int32_t* count) {
+    ARG_TRY(ctx, A && winv && info && lda >= n && B >= 1 && (!list || (count && slots >= 1)));
     if (n == 0) return MADQP_OK;
     HIP_TRY(ctx, hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), ctx->stream));
-    CholBatch c{ctx, A, lda, n, sA, winv, sW, info, B, skip};
+    CholBatch c{ctx, A, lda, n, sA, winv, sW, info, list ? slots : B, list ? nullptr : skip, list, count};
     return bfactor_range(c, 0, n);
 }
 
@@ -1593,7 +1687,8 @@ extern "C" int32_t madqp_chol_factor_begin(madqp_chol* s, double* A, int64_t lda
 extern "C" int32_t madqp_chol_factor_panel(madqp_chol* s, int64_t j0, int64_t w) {
     if (!s) return MADQP_ERR_ARG;
     ARG_TRY(s->ctx, panel_ok(s, j0, w));
-    return factor_range(s, s->A, s->lda, j0, w);
+    const int32_t r = factor_range(s, s->A, s->lda, j0, w);
+    return r ? r : invert_blocks(s, s->A, s->lda, j0, w);  // (the caller packs / reads the images of this panel next)
 }
 
 // buf = [info, 0 | inverse diagonal blocks of the panel | L[j0:n, j0+c] for c = 0..w-1]

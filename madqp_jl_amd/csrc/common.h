@@ -137,6 +137,11 @@ struct GemmBatch {
     int64_t B;
     int64_t sX, sY, sC, sCin, sD;
     const int32_t* skip;
+    // compacted form (the masked x100-retry rounds of the batched engine): the launch has B "slots" in grid.y and slot y
+    // works off the problems list[y], list[y + B], .. < *count -- with nothing to retry (the usual case) every workgroup
+    // of the launch leaves after one load instead of B problems' worth of workgroups reading their skip word
+    const int32_t* list = nullptr;
+    const int32_t* count = nullptr;
 };
 int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int64_t* cols = nullptr,
                       int64_t ncols = 0, const GemmBatch* batch = nullptr);
@@ -145,7 +150,8 @@ void madqp_gemm_release_tables(madqp_ctx* ctx);
 
 // chol.hip: recursive blocked factorisation of B equally sized matrices (see there)
 int32_t madqp_chol_factor_batched(madqp_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t sA, double* winv,
-                                  int64_t sW, int32_t* info, int64_t B, const int32_t* skip);
+                                  int64_t sW, int32_t* info, int64_t B, const int32_t* skip, int64_t slots = 0,
+                                  const int32_t* list = nullptr, const int32_t* count = nullptr);
 
 // gemv.hip (internal entry with explicit class)
 int32_t madqp_gemv_impl(madqp_ctx* ctx, int32_t trans, int64_t rows, int64_t cols, double alpha,

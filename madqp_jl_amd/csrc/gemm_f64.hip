@@ -175,6 +175,24 @@ __device__ __forceinline__ void gemm_tile(const KArgs& ka, const GemmArgs& g, in
 
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
     __shared__ __attribute__((aligned(16))) double lds[4 * TILE_DOUBLES];
+    if (ka.batch.list) {  // compacted batch (GemmBatch::list): the problems of this slot, one after the other
+        const int cnt = __builtin_amdgcn_readfirstlane(*ka.batch.count);
+        const int bid = blockIdx.x, T = ka.ntiles;
+        const int xcd = bid & 7, q = T >> 3, r = T & 7;
+        const int t = ka.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3) : bid;
+        for (int pb = blockIdx.y; pb < cnt; pb += gridDim.y) {
+            const int64_t b = ka.batch.list[pb];
+            GemmArgs g = ka.g;
+            g.X += b * ka.batch.sX;
+            g.Y += b * ka.batch.sY;
+            g.C += b * ka.batch.sC;
+            if (g.Cin) g.Cin += b * ka.batch.sCin;
+            if (g.dvec) g.dvec += b * ka.batch.sD;
+            gemm_tile(ka, g, t, bid, lds);
+            __syncthreads();  // the LDS image is reused
+        }
+        return;
+    }
     GemmArgs g = ka.g;
     if (!gemm_select(ka, g)) return;
     // Tile selection: the table is cut into 8 contiguous chunks, one per XCD (workgroup ids equal
@@ -440,6 +458,30 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
     extern unsigned long long* madqp_stamp_buffer;
     ka.stamps = madqp_stamp_buffer;
 #endif
+    // Tail split (round 4): a launch of one to three rounds whose LAST round is partly empty -- the assembly of a
+    // mid-size matrix: 820 tiles on 512 slots are 1.6 rounds that take the time of 2 -- runs its whole rounds as they are
+    // and cuts only the tiles of the last round into S chunks of K (more, shorter pieces that fill the chip), summed in
+    // chunk order by splitk_reduce_kernel like every split launch: same result on every run.  S from the same cost model
+    // as above (microseconds: 0.216 per unit of K and 10 per piece, 0.05 per partial tile of the second pass).
+    int64_t tail_S = 0, tail_n = 0;
+    static const int tail_on = getenv("MADQP_GEMM_TAILSPLIT") ? atoi(getenv("MADQP_GEMM_TAILSPLIT")) : 1;
+    if (split_on && tail_on && !batch && ka.ksplit == 1 && a.K >= 1024 && ctx->gemm_cap_slots == 0 &&
+        (int64_t)ka.ntiles > ctx->gemm_slots && (int64_t)ka.ntiles < 4 * ctx->gemm_slots) {
+        const int64_t slots = ctx->gemm_slots, tl = (int64_t)ka.ntiles % slots;
+        if (tl > 0 && 10 * tl < 8 * slots) {
+            const double tile = 0.216 * (double)a.K + 10.0;
+            double best = tile * 0.93;  // (the last round as it is; worth it only with a clear gain)
+            for (int64_t S = 2; S <= 8 && a.K / S >= 256; ++S) {
+                const double rounds = std::ceil((double)tl * (double)S / (double)slots);
+                const double c = rounds * (0.216 * (double)a.K / (double)S + 10.0) + 0.05 * (double)S * (double)tl;
+                if (c < best) {
+                    best = c;
+                    tail_S = S;
+                }
+            }
+            if (tail_S) tail_n = tl;
+        }
+    }
     // Long launches are cut into segments of 64 rounds of resident workgroups.  Equal-cost tiles
     // that start together sweep K in lockstep and share their operand panels through the XCD's
     // L2; over many rounds that lockstep diffuses away (measured at n = 50000, K = 20480: 0.93-1.3 TB
@@ -448,7 +490,7 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
     static const int seg_rounds = getenv("MADQP_GEMM_SEG_ROUNDS") ? atoi(getenv("MADQP_GEMM_SEG_ROUNDS")) : 64;
     const int64_t seg = seg_rounds > 0 ? (int64_t)seg_rounds * ctx->gemm_slots : (int64_t)ka.ntiles;
     const int32_t* table0 = ka.table;
-    const int32_t total = ka.ntiles;
+    const int32_t total = ka.ntiles - (int32_t)tail_n;  // (tiles launched whole)
     ProfScope ps(ctx, prof_cls);
     // capped launch (ctx->gemm_cap_slots, set by dist.hip around a bulk trailing update): a persistent grid that leaves
     // workgroup slots free for the kernels of other streams
@@ -469,6 +511,24 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
         hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3(ka.ntiles, gy), dim3(NTHREADS), 0, ctx->stream, ka);
         LAUNCH_CHECK(ctx);
         if (cnt == total - off) break;
+    }
+    if (tail_n) {  // the tiles of the last round, K-split
+        const int64_t chunk = ((a.K + tail_S - 1) / tail_S + BK - 1) / BK * BK;
+        const int64_t S = (a.K + chunk - 1) / chunk;
+        const size_t bytes = (size_t)S * tail_n * BM * BN * sizeof(double);
+        int32_t r = madqp_work_reserve(ctx, bytes);
+        if (r) return r;
+        ka.table = table0 + total;
+        ka.ntiles = (int32_t)tail_n;
+        ka.ksplit = (int32_t)S;
+        ka.kchunk = chunk;
+        ka.work = ctx->d_work;
+        hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3(ka.ntiles, (unsigned)S), dim3(NTHREADS), 0, ctx->stream, ka);
+        LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)tail_n), dim3(256), 0, ctx->stream, a, table0 + total,
+                           (int32_t)tail_n, (int32_t)S, ka.work);
+        LAUNCH_CHECK(ctx);
+        return MADQP_OK;
     }
     if (ka.ksplit > 1) {  // (a split launch is always a single segment: few tiles)
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(total), dim3(256), 0, ctx->stream, a, table0, total, ka.ksplit,
