@@ -1059,6 +1059,7 @@ struct MidArgs {
     int32_t pack;  // tiles per workgroup (1 or 2); the diagonal tile always has its workgroup to itself
     int32_t npair;  // pack == 2: workgroups 1 .. npair take two tiles, the ones behind them one (see chol_factor_enqueue)
     int32_t lite;   // the diagonal workgroup factors only (MODE 1); the inverse images follow in one launch at the end
+    int32_t dsyrk;  // the diagonal workgroup updates its tile with mid_diag_syrk (all eight waves, operand fetched at once)
     double* winv;
     int32_t* info;
 };
@@ -1074,6 +1075,97 @@ __device__ unsigned long long madqp_mid_stamps[64][16];  // diagnostic build onl
 #endif
 constexpr int MID_THREADS = 512;
 constexpr int MID_BARRIERS = NB / BK + 1;  // barriers of one K = 128 main loop (both flavours)
+
+// ---- the diagonal workgroup's own update (round 4): S <- C_kk - R R' with R = L[block row k, panel k-1] ------------------
+// Through the GEMM main loop (one 128 x 128 tile on four waves, K = 128 in eight stages with ONE stage of prefetch) this
+// took 18-22 us of the ~56 us chain of a block step (tools/mid_probe): a single workgroup has nobody to hide the latency of
+// its eight dependent stage loads behind, and it computes all 64 sub-tiles where potf2 reads 36.  Here the whole operand
+// (128 KB: both operands of a SYRK are the same block row) is fetched at once -- every load of the workgroup in flight
+// together, one latency -- into a k-major LDS image, all eight waves take the 36 lower 16 x 16 sub-tiles (a row pair
+// I, 7-I per two waves: nine tiles sharing their fragments), and the result goes straight to the LDS image of potf2.
+// D'[m][n] = sum_k R(16 J + m, k) R(16 I + n, k): A-operand <- fragment of block row J, B-operand <- block row I, so lane l holds
+// element (row 16 I + (l & 15), column 16 J + (l >> 4) + 4 v): rows are the fast index of every global and LDS access.
+constexpr int XS_LD = 144;  // k-row stride of the operand image (= 16 mod 32: the two k-rows of a half-wave read hit disjoint banks)
+static_assert(NB * XS_LD <= P2_S_DOUBLES + P2_WD_DOUBLES, "the operand image fits the diagonal kernel's LDS");
+#ifdef MADQP_MID_STAMPS
+#define DS_STAMP(slot)                                                                                   \
+    do {                                                                                                 \
+        if (threadIdx.x == 0) madqp_mid_stamps[kstep & 63][(slot)] = __builtin_amdgcn_s_memrealtime();   \
+    } while (0)
+#else
+#define DS_STAMP(slot)
+#endif
+__device__ __forceinline__ void mid_diag_syrk(const double* __restrict__ Ckk, const double* __restrict__ R, int64_t lda, int nb,
+                                              double* __restrict__ smem, int kstep) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = lane & 15, hi = lane >> 4;
+    // this wave's tiles: row pair (p, 7 - p) has 9 lower tiles, waves 2p / 2p + 1 take the first 5 / last 4 of them
+    const int p = wave >> 1, first = (wave & 1) ? 5 : 0, cnt = (wave & 1) ? 4 : 5;
+    int tI[5], tJ[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        int q = first + (u < cnt ? u : cnt - 1);  // (a short list repeats its last tile; not stored twice)
+        // tiles of the pair in order: (p, 0..p), then (7-p, 0..7-p)
+        tI[u] = (q <= p) ? p : 7 - p;
+        tJ[u] = (q <= p) ? q : q - (p + 1);
+    }
+    // 1. the operand: 16 x 16-byte loads per thread, all in flight; pair index e = tid + 512 q: column c = e / 64, rows 2 (e % 64)
+    double2_t rv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + MID_THREADS * q, c = e >> 6, i = 2 * (e & 63);
+        rv[q] = *reinterpret_cast<const double2_t*>(R + i + (int64_t)c * lda);
+    }
+    // 2. the tile itself, negated (the products are added, the result is negated back): element (r = 16 I + lo, c = 16 J + hi + 4 v)
+    double4_t acc[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            int c = 16 * tJ[u] + hi + 4 * v;
+            c = c < nb ? c : nb - 1;  // (columns beyond the order need not exist in the caller's buffer: any value will do)
+            acc[u][v] = -Ckk[(16 * tI[u] + lo) + (int64_t)c * lda];
+        }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + MID_THREADS * q, c = e >> 6, i = 2 * (e & 63);
+        *reinterpret_cast<double2_t*>(smem + c * XS_LD + i) = rv[q];
+    }
+    __syncthreads();
+    DS_STAMP(4);
+    const double* xa[5];
+    const double* xb[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        xa[u] = smem + hi * XS_LD + 16 * tJ[u] + lo;  // A[m = lo][k = hi + 4 s] = R(16 J + lo, 4 s + hi)
+        xb[u] = smem + hi * XS_LD + 16 * tI[u] + lo;  // B[k = hi + 4 s][n = lo] = R(16 I + lo, 4 s + hi)
+    }
+#pragma unroll 2
+    for (int s4 = 0; s4 < 32; ++s4) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u][4 * s4 * XS_LD], xb[u][4 * s4 * XS_LD], acc[u], 0, 0, 0);
+    }
+    DS_STAMP(5);
+    __syncthreads();  // every wave has read its fragments: the image becomes potf2's S[c * LDS_LD + r]
+    DS_STAMP(6);
+    // 3. lower tiles -> S (upper triangle of the diagonal sub-tiles zero, identity beyond the order of a short last block);
+    //    the strictly upper sub-tiles, which nobody computes, are the inverse's work area and must be zero: every
+    //    off-diagonal lower tile (I, J) zeroes its mirror image (J, I) -- all 28 of them, no index arithmetic
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        if (u >= cnt) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 16 * tI[u] + lo, c = 16 * tJ[u] + hi + 4 * v;
+            double x = -acc[u][v];
+            if (r >= nb || c >= nb) x = (r == c) ? 1.0 : 0.0;
+            smem[c * LDS_LD + r] = (r >= c) ? x : 0.0;
+            if (tI[u] != tJ[u]) smem[(16 * tI[u] + hi + 4 * v) * LDS_LD + 16 * tJ[u] + lo] = 0.0;  // element (16 J + lo, 16 I + hi + 4 v)
+        }
+    }
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     __shared__ __attribute__((aligned(16))) double smem[P2_S_DOUBLES + P2_WD_DOUBLES];
@@ -1106,7 +1198,12 @@ __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     double* lds = smem + half * (4 * TILE_DOUBLES);
     double4_t acc[4][4];
 
-    if (k > 0) {
+    const bool own_syrk = diag && k > 0 && a.dsyrk;  // (uniform over the workgroup)
+    if (own_syrk) {
+        mid_diag_syrk(a.A + i0 + i0 * a.lda, a.A + i0 + (int64_t)(k - 1) * NB * a.lda, a.lda,
+                      (int)((a.n - i0 < NB) ? (a.n - i0) : NB), smem, k);
+        MID_STAMP(1);
+    } else if (k > 0) {
         GemmArgs g{};
         g.X = a.A + (int64_t)(k - 1) * NB * a.lda;
         g.Y = g.X;
@@ -1152,7 +1249,7 @@ __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     // the diagonal tile: accumulators -> LDS image S[c*LDS_LD + r] (lower triangle, identity padding), factor, invert
     double* S = smem;
     const int nb = (int)((a.n - i0 < NB) ? (a.n - i0) : NB);
-    if (k > 0) {
+    if (k > 0 && !own_syrk) {
         // (the main loop ends with a barrier after its last LDS read: the staging buffers are free)
         if (half == 0) {
 #pragma unroll
@@ -1430,6 +1527,7 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
             explicit ProfMute(madqp_ctx* ctx_) : c(ctx_), saved(ctx_->prof) { c->prof = 0; }
             ~ProfMute() { c->prof = saved; }
         } mute(ctx);
+        static const bool mid_dsyrk = !(getenv("MADQP_CHOL_MID_DSYRK") && atoi(getenv("MADQP_CHOL_MID_DSYRK")) == 0);
         for (int32_t k = 0; k < nblk; ++k) {
             {
                 const int64_t rem = nblk - k, ntiles = (k > 0) ? rem * (rem + 1) / 2 : 1;
@@ -1448,7 +1546,8 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
                     }
                 }
                 hipLaunchKernelGGL(chol_mid_step_kernel, dim3(grid), dim3(MID_THREADS), 0, ctx->stream,
-                                   MidArgs{A, lda, n, nblk, k, pack, npair, chol_lite() ? 1 : 0, s->winv, s->d_info});
+                                   MidArgs{A, lda, n, nblk, k, pack, npair, chol_lite() ? 1 : 0, mid_dsyrk ? 1 : 0, s->winv,
+                                           s->d_info});
                 LAUNCH_CHECK(ctx);
             }
             const int64_t jb = (int64_t)k * NB;

@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < nblk && k < 64; ++k) {
             auto us = [&](int a, int b) { return (double)(st[k][b] - st[k][a]) * 0.01; };
             printf("k=%2d  diag %5.1f %5.1f %5.1f | other %5.1f", k, us(0, 1), us(1, 2), us(2, 3), us(8, 9));
+            if (st[k][4]) printf(" | syrk: operand in LDS +%.1f, products +%.1f, all waves done +%.1f, S written +%.1f", us(0, 4), us(4, 5), us(5, 6), us(6, 1));
             if (k + 1 < nblk) printf(" | next step starts +%.1f after the diagonal workgroup ends", (double)(st[k + 1][0] - st[k][3]) * 0.01);
             printf("\n");
         }
