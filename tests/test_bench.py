@@ -207,3 +207,27 @@ def test_one_gpu_line_has_the_reference_rate_definitions():
                     regularization=mpc.FixedRegularization(1e-8, -1e-8), step_rule=mpc.AdaptiveStep(0.995), mu_min=1e-12,
                     max_iter=300)
     assert ws["iter"] == ref["iter"] and abs(ws["objective"] - ref["objective"]) <= 1e-9 * max(1.0, abs(ref["objective"]))
+
+
+def test_under_an_external_launcher_the_process_is_one_of_the_ranks():
+    """The driver's N > 1 form: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` -- WORLD_SIZE
+    equals --gpus, nothing is spawned, rank 0 prints the one line and says who started the ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MADQP_BENCH_SPAWNED_BY")}
+    env.update(PYTHONPATH=os.pathsep.join([os.path.join(root, "tests"), root, env.get("PYTHONPATH", "")]),
+               OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MADQP_BENCH_TEST_DOUBLE="bench_double:Double")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29591", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "40",
+           "--ncon", "16", "--driver", "python", "--no-cpu-baseline", "--extra-timeout", "120"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_gpus_requested"] == 2 and out["scaling"] == "strong"
+    assert out["ranks"]["started_by"] == "an external launcher" and out["comm"]["world_size"] == 2

@@ -40,11 +40,8 @@ def factor_range(n, j0, w):
     if w <= NB:
         if j0 + w < n:
             below = n - j0 - w
-            if w == NB and below <= 24576:  # chol.hip factor_block: panel_inv_kernel, 32 rows per workgroup
-                npad = (n + NB - 1) // NB * NB
-                sched.append(("trsm32", below, w, w, (npad - j0 - NB) // 32))
-            else:
-                sched.append(("trsm", below, w, w, (below + 127) // 128))
+            # chol.hip factor_block (round 4): panel_sub16_kernel, block substitution, 64 rows per workgroup
+            sched.append(("trsm64", below, w, w, (below + 63) // 64))
         return
     h = ((w + NB - 1) // NB + 1) // 2 * NB
     factor_range(n, j0, h)
@@ -61,7 +58,7 @@ while J0 < n:
     factor_range(n, J0, W)
     J0 += W
 f = glob.glob(sys.argv[1])[0]
-rows = [r for r in csv.DictReader(open(f)) if "gemm_tn" in r["Kernel_Name"] or "panel_inv" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "gemm_tn" in r["Kernel_Name"] or "panel_sub16" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in rows]
 grids = [int(r["Grid_Size_X"]) // 256 for r in rows]
@@ -71,15 +68,24 @@ nsy, acc = 0, 0
 while acc < syrk_tiles:  # the assembly may be cut into several launches (segments)
     acc += grids[nsy]
     nsy += 1
-print(len(sched), "gemm launches per factorization;", len(rows), "in trace;", nsy, "assembly launches")
-seg = list(zip(sched, durs[nsy:nsy + len(sched)], grids[nsy:nsy + len(sched)]))
+print(len(sched), "gemm-class launches per factorization in the host schedule;", len(rows), "in trace;", nsy, "assembly launches")
+# a scheduled product may be several launches (64-round segments; whole rounds + the K-split tail of madqp_gemm_tn): consume
+# launches until their tiles cover the scheduled ones, add their times
+seg, pos = [], nsy
+for item in sched:
+    need, got, d = item[4], 0, 0.0
+    while got < need and pos < len(rows):
+        got += grids[pos]
+        d += durs[pos]
+        pos += 1
+    seg.append((item, d, got))
 agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
 mismatch = 0
 for (kind, M, N, K, t), d, g in seg:
     mismatch += int(t != g)  # replayed schedule vs traced grid (labels are approximate if > 0)
     t = g
-    if kind == "trsm32":  # 32 x 128 outputs per workgroup, the zero half of W skipped: flops of the full product for comparison
-        agg[kind][0] += 2.0 * t * 32 * 128 * K
+    if kind == "trsm64":  # 64 x 128 outputs per workgroup by block substitution: flops of the full product for comparison
+        agg[kind][0] += 2.0 * t * 64 * 128 * K
         agg[kind][1] += d
         agg[kind][2] += 1
         continue
