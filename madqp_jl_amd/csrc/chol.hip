@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.h"
+#include "mid_plan.inc"
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
@@ -1060,21 +1061,22 @@ struct MidArgs {
     int32_t npair;  // pack == 2: workgroups 1 .. npair take two tiles, the ones behind them one (see chol_factor_enqueue)
     int32_t lite;   // the diagonal workgroup factors only (MODE 1); the inverse images follow in one launch at the end
     int32_t dsyrk;  // the diagonal workgroup updates its tile with mid_diag_syrk (all eight waves, operand fetched at once)
+    int32_t two;    // two panels per trailing pass (see chol_factor_enqueue): workgroup 1 = the next diagonal tile (one panel)
+    const uint32_t* plan;  // the units of this step (mid_plan_build, mid_plan.inc) or nullptr; one tile per workgroup then
     double* winv;
     int32_t* info;
 };
 #ifdef MADQP_MID_STAMPS
-__device__ unsigned long long madqp_mid_stamps[64][16];  // diagnostic build only (tools/mid_probe.cpp)
+__device__ unsigned long long madqp_mid_stamps[64][24];  // diagnostic build only (tools/mid_probe.cpp)
 #define MID_STAMP(slot)                                                                                              \
     do {                                                                                                             \
-        if (threadIdx.x == 0 && blockIdx.x <= 1)                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x <= 2)                                                                     \
             madqp_mid_stamps[a.k & 63][8 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime();                  \
     } while (0)
 #else
 #define MID_STAMP(slot)
 #endif
 constexpr int MID_THREADS = 512;
-constexpr int MID_BARRIERS = NB / BK + 1;  // barriers of one K = 128 main loop (both flavours)
 
 // ---- the diagonal workgroup's own update (round 4): S <- C_kk - R R' with R = L[block row k, panel k-1] ------------------
 // Through the GEMM main loop (one 128 x 128 tile on four waves, K = 128 in eight stages with ONE stage of prefetch) this
@@ -1167,6 +1169,8 @@ __device__ __forceinline__ void mid_diag_syrk(const double* __restrict__ Ckk, co
     __syncthreads();
 }
 
+// MODE 0: the tiles of the step in launch order (pack / npair / two); 1: planned units (a.plan).
+template <int MODE>
 __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     __shared__ __attribute__((aligned(16))) double smem[P2_S_DOUBLES + P2_WD_DOUBLES];
     static_assert(P2_S_DOUBLES + P2_WD_DOUBLES >= 8 * TILE_DOUBLES, "two GEMM halves fit the diagonal kernel's LDS");
@@ -1178,18 +1182,75 @@ __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     const int k = a.k, rem = a.nblk - k;
     const bool diag = (blockIdx.x == 0);
     MID_STAMP(0);
-    // tile t = i'(i'+1)/2 + j' (0 <= j' <= i' < rem) is (k + i', k + j'); t = 0, the diagonal tile, is workgroup 0
-    const int ntiles = rem * (rem + 1) / 2;
-    const int wg = (int)blockIdx.x - 1;  // 0-based among the workgroups of the trailing tiles
-    const bool paired = a.pack == 2 && wg < a.npair;
-    const int t = diag ? 0 : (paired || a.pack == 1 ? 1 + a.pack * wg + half : 1 + 2 * a.npair + (wg - a.npair));
-    const bool active = diag ? (half == 0) : (t < ntiles && (paired ? true : half == 0));
-    int ip = 0, jp = 0;
-    if (active && !diag) {
-        ip = (int)((sqrtf(1.0f + 8.0f * (float)t) - 1.0f) * 0.5f);
-        while (ip * (ip + 1) / 2 > t) --ip;
-        while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
-        jp = t - ip * (ip + 1) / 2;
+    int ip = 0, jp = 0, kpan = 1;  // tile (k + ip, k + jp); panels this tile receives (the last kpan ones before k)
+    int pan0 = k - 1;              // ... starting with this one
+    bool active;
+    if (MODE != 0) {
+        // Planned units (round 4, mid_plan_build): workgroup 1 + u takes unit u of this step's list -- one trailing tile
+        // (row, column) and the panels it receives in one product; the other four waves keep its barriers company.
+        // (Measured and dropped: two units per workgroup in the steps of more than one round of tiles -- 6.15 against
+        // 5.77 ms per factorisation at n = 8 000.)
+        active = (half == 0);
+        if (!diag) {
+            const uint32_t e = a.plan[(int)blockIdx.x - 1];
+            ip = (int)(e & 255u) - k;
+            jp = (int)((e >> 8) & 255u) - k;
+            pan0 = (int)((e >> 16) & 255u);
+            kpan = (int)(e >> 24);
+        }
+        kpan = __builtin_amdgcn_readfirstlane(kpan);
+        pan0 = __builtin_amdgcn_readfirstlane(pan0);
+    } else if (MODE == 0 && !a.two) {
+        // tile t = i'(i'+1)/2 + j' (0 <= j' <= i' < rem) is (k + i', k + j'); t = 0, the diagonal tile, is workgroup 0
+        const int ntiles = rem * (rem + 1) / 2;
+        const int wg = (int)blockIdx.x - 1;  // 0-based among the workgroups of the trailing tiles
+        const bool paired = a.pack == 2 && wg < a.npair;
+        const int t = diag ? 0 : (paired || a.pack == 1 ? 1 + a.pack * wg + half : 1 + 2 * a.npair + (wg - a.npair));
+        active = diag ? (half == 0) : (t < ntiles && (paired ? true : half == 0));
+        if (active && !diag) {
+            ip = (int)((sqrtf(1.0f + 8.0f * (float)t) - 1.0f) * 0.5f);
+            while (ip * (ip + 1) / 2 > t) --ip;
+            while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
+            jp = t - ip * (ip + 1) / 2;
+        }
+    } else if (MODE == 0) {
+        // Two panels per pass (round 4).  Step k touches only the tile COLUMNS of its own parity, k, k+2, k+4, ..: each
+        // receives the two panels k-2 and k-1 in ONE product (K = 256; step 1: panel 0 alone), so a trailing tile is read
+        // and written every second step -- half the HBM traffic that bound the first 17 steps.  Column k itself is in
+        // that class, so the panel of this step is up to date; its diagonal tile is the diagonal workgroup's (one panel:
+        // the tile got panel k-2 as "next diagonal tile" in step k-1), and workgroup 1 gives the NEXT diagonal tile
+        // (k+1, k+1) panel k-1 alone, so that step k+1 again finds a tile that lacks one panel (one SYRK, K = 128).
+        const bool has_exc = (k + 1 < a.nblk);
+        const int wg = (int)blockIdx.x - 1 - (has_exc ? 1 : 0);  // 0-based among the workgroups of the class tiles
+        int ncls = rem - 1;
+        for (int c = 1; 2 * c < rem; ++c) ncls += rem - 2 * c;
+        if (diag) {
+            active = (half == 0);
+        } else if (has_exc && blockIdx.x == 1) {  // the next diagonal tile, alone in its workgroup (its K differs)
+            active = (half == 0);
+            ip = jp = 1;
+        } else {
+            const bool paired = a.pack == 2 && wg < a.npair;
+            const int u = paired || a.pack == 1 ? a.pack * wg + half : 2 * a.npair + (wg - a.npair);
+            active = u < ncls && (paired ? true : half == 0);
+            kpan = (k >= 2) ? 2 : 1;
+            if (active) {
+                if (u < rem - 1) {
+                    jp = 0;
+                    ip = 1 + u;
+                } else {
+                    int v = u - (rem - 1), c = 1;
+                    while (v >= rem - 2 * c) {
+                        v -= rem - 2 * c;
+                        ++c;
+                    }
+                    jp = 2 * c;
+                    ip = jp + v;
+                }
+            }
+        }
+        kpan = __builtin_amdgcn_readfirstlane(kpan);
+        pan0 = k - kpan;
     }
     ip = __builtin_amdgcn_readfirstlane(ip);  // wave-uniform: the LDS-DMA rows are addressed from scalar registers
     jp = __builtin_amdgcn_readfirstlane(jp);
@@ -1205,14 +1266,15 @@ __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
         MID_STAMP(1);
     } else if (k > 0) {
         GemmArgs g{};
-        g.X = a.A + (int64_t)(k - 1) * NB * a.lda;
+        g.X = a.A + (int64_t)pan0 * NB * a.lda;  // kpan panels from pan0 on: their columns are contiguous
         g.Y = g.X;
         g.ldx = g.ldy = a.lda;
         g.M = g.N = a.n;
         g.Mread = g.Nread = npad;
-        g.K = NB;
-        if (!active) {  // the other half of the workgroup has a tile: keep its barriers company
-            for (int b = 0; b < MID_BARRIERS; ++b) __builtin_amdgcn_s_barrier();
+        g.K = kpan * NB;
+        if (!active) {  // the other half of the workgroup has a tile: keep its barriers company (same K: see the pairing)
+            const int nbar = kpan * (NB / BK) + 1;
+            for (int b = 0; b < nbar; ++b) __builtin_amdgcn_s_barrier();
         } else {
             // the accumulators start at -C_ij (loads in flight while the first stage is staged; rows up to the padded
             // order exist, what lies beyond n or above the diagonal is never stored) and come back negated
@@ -1243,6 +1305,7 @@ __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
                 }
             }
         }
+        MID_STAMP(7);
     }
     if (!diag) return;
 
@@ -1351,6 +1414,8 @@ extern "C" int32_t madqp_chol_destroy(madqp_chol* s) {
     if (s->tmp) (void)hipFree(s->tmp);
     if (s->d_jobs) (void)hipFree(s->d_jobs);
     if (s->d_info) (void)hipFree(s->d_info);
+    if (s->d_mid_plan) (void)hipFree(s->d_mid_plan);
+    delete[] s->mid_units;
     delete s;
     return MADQP_OK;
 }
@@ -1505,6 +1570,49 @@ static int32_t factor_range(madqp_chol* s, double* A, int64_t lda, int64_t j0, i
     return factor_range(s, A, lda, j0 + h, w - h);
 }
 
+// ---- mid-size schedule: which trailing columns a block step visits (round 4) ---------------------------------------
+// The right-looking schedule rewrote the whole trailing matrix in every step; its first steps were bound by that (two
+// rounds of tiles per step at n = 5 000) while the later ones wait for the chain diagonal tile -> panel -> diagonal tile
+// with most CUs idle.  The update of column j with panel p is due only at step j, so the work can be moved: tile column
+// j carries upto[j] (panels 0 .. upto[j]-1 applied); step k VISITS a column by applying up to MID_Q of its pending panels
+// to all its tiles in one product (K = 128 q, one tile per workgroup, a column at most once per step).  Every step
+// visits column k (completing it: its panel is solved next) and column k+1 (so that the next diagonal tile lacks panel
+// k alone, the diagonal workgroup's own SYRK), then the columns with the least slack -- steps until the column is due
+// minus the visits it still needs -- while the step's budget of `rounds` x `cap` tiles lasts; a column whose slack is
+// used up is visited whatever the budget.  `rounds` is the smallest count for which no visit ever needs more than
+// MID_Q panels: 1 up to n = 5 120 on 256 CUs (every step then fits the shadow of the chain: 40 steps of ~47 us at
+// n = 5 000 instead of 8 of them at ~90 us), 2-4 up to 10 240.  The plan depends on (number of blocks, cap) only.
+// builds and uploads the plan of s (once); false: no plan (the caller runs the two-panel schedule)
+static bool mid_plan_build(madqp_chol* s, int nblk, int cap) {
+    if (s->mid_plan_state) return s->mid_plan_state > 0;
+    s->mid_plan_state = -1;
+    if (nblk > 255 || cap < 1) return false;
+    std::vector<std::vector<MidVisit>> steps;
+    std::vector<int32_t> units;
+    bool ok = false;
+    for (int rounds = 1; rounds <= 64 && !ok; ++rounds) ok = mid_plan_steps(nblk, rounds * cap, steps, units);
+    if (!ok) return false;
+    std::vector<uint32_t> w;
+    s->mid_units = new (std::nothrow) int32_t[2 * nblk];
+    if (!s->mid_units) return false;
+    for (int k = 0; k < nblk; ++k) {
+        s->mid_units[nblk + k] = (int32_t)w.size();
+        mid_plan_units(nblk, k, steps[k], w);
+        s->mid_units[k] = (int32_t)w.size() - s->mid_units[nblk + k];
+        if (s->mid_units[k] != units[k]) return false;
+    }
+    if (w.empty()) w.push_back(0);
+    if (hipMalloc(&s->d_mid_plan, w.size() * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        s->d_mid_plan = nullptr;
+        return false;
+    }
+    // (synchronous, pageable source: the copy has left `w` when the call returns; once per handle)
+    if (hipMemcpy(s->d_mid_plan, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return false;
+    s->mid_plan_state = 1;
+    return true;
+}
+
 // Everything of a factorisation except reading its info back: the launches are on the stream, info sits in s->d_info.
 static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
     madqp_ctx* ctx = s->ctx;
@@ -1528,26 +1636,47 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
             ~ProfMute() { c->prof = saved; }
         } mute(ctx);
         static const bool mid_dsyrk = !(getenv("MADQP_CHOL_MID_DSYRK") && atoi(getenv("MADQP_CHOL_MID_DSYRK")) == 0);
+        // two panels per trailing pass (see the kernel): needs the diagonal workgroup's own SYRK
+        static const bool mid_two = mid_dsyrk && !(getenv("MADQP_CHOL_MID_TWO") && atoi(getenv("MADQP_CHOL_MID_TWO")) == 0);
+        // planned visits (mid_plan_build) unless switched off; the two-panel schedule otherwise
+        static const bool mid_lazy = mid_dsyrk && !(getenv("MADQP_CHOL_MID_LAZY") && atoi(getenv("MADQP_CHOL_MID_LAZY")) == 0);
+        const bool planned = mid_lazy && mid_plan_build(s, nblk, ctx->gemm_slots / 2 - 1);
         for (int32_t k = 0; k < nblk; ++k) {
-            {
-                const int64_t rem = nblk - k, ntiles = (k > 0) ? rem * (rem + 1) / 2 : 1;
+            if (planned) {
+                hipLaunchKernelGGL(chol_mid_step_kernel<1>, dim3((unsigned)(1 + s->mid_units[k])), dim3(MID_THREADS), 0,
+                                   ctx->stream,
+                                   MidArgs{A, lda, n, nblk, k, 1, 0, chol_lite() ? 1 : 0, 1, 0,
+                                           s->d_mid_plan + s->mid_units[nblk + k], s->winv, s->d_info});
+                LAUNCH_CHECK(ctx);
+            } else {
+                const int64_t rem = nblk - k;
+                int64_t nt, extra = 0;  // tiles shared out by pack/npair; workgroups before them besides the diagonal one
+                if (k == 0) {
+                    nt = 0;
+                } else if (!mid_two) {
+                    nt = rem * (rem + 1) / 2 - 1;
+                } else {
+                    nt = rem - 1;  // column k below its diagonal tile, then columns k+2, k+4, ..
+                    for (int64_t c = 1; 2 * c < rem; ++c) nt += rem - 2 * c;
+                    extra = (k + 1 < nblk) ? 1 : 0;  // the next diagonal tile
+                }
                 // One workgroup per CU (LDS), one or two tiles each.  Up to a round of single tiles: singles; up to a round
                 // of pairs: pairs; beyond that -- two rounds -- as few pairs as two rounds of workgroups need, FIRST in the
                 // grid, singles behind them: a CU then works off three tiles (pair + single or three singles, 44 + 22 us)
                 // instead of four (two pairs, 88 us) whenever three per CU are enough (up to 765 tiles).
-                const int64_t nt = ntiles - 1, cus = ctx->gemm_slots / 2 - 1;  // (the diagonal workgroup holds a CU)
+                const int64_t cus = ctx->gemm_slots / 2 - 1 - extra;  // (the diagonal workgroup holds a CU)
                 int32_t pack = (nt > cus) ? 2 : 1, npair = 0;
-                unsigned grid = (unsigned)(1 + (nt + pack - 1) / pack);
+                unsigned grid = (unsigned)(1 + extra + (nt + pack - 1) / pack);
                 if (pack == 2) {
                     npair = (int32_t)((nt + 1) / 2);
                     if (nt > 2 * cus && nt - 2 * cus <= cus) {
                         npair = (int32_t)(nt - 2 * cus);
-                        grid = (unsigned)(1 + npair + (nt - 2 * (int64_t)npair));
+                        grid = (unsigned)(1 + extra + npair + (nt - 2 * (int64_t)npair));
                     }
                 }
-                hipLaunchKernelGGL(chol_mid_step_kernel, dim3(grid), dim3(MID_THREADS), 0, ctx->stream,
-                                   MidArgs{A, lda, n, nblk, k, pack, npair, chol_lite() ? 1 : 0, mid_dsyrk ? 1 : 0, s->winv,
-                                           s->d_info});
+                hipLaunchKernelGGL(chol_mid_step_kernel<0>, dim3(grid), dim3(MID_THREADS), 0, ctx->stream,
+                                   MidArgs{A, lda, n, nblk, k, pack, npair, chol_lite() ? 1 : 0, mid_dsyrk ? 1 : 0,
+                                           mid_two ? 1 : 0, nullptr, s->winv, s->d_info});
                 LAUNCH_CHECK(ctx);
             }
             const int64_t jb = (int64_t)k * NB;

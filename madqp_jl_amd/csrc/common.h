@@ -196,4 +196,10 @@ struct madqp_chol {
     int64_t lda;
     bool factored;
     int64_t npos;  // quasi-definite mode (madqp_chol_set_signature): A = L diag(I_npos, -I) L'; npos == n: Cholesky
+    // mid-size schedule (chol.hip, mid_plan_build): which trailing tiles each block step updates, with which panels;
+    // built at the first factorisation.  d_mid_plan: the packed units of all steps (mid_plan.inc); mid_units[k] /
+    // mid_units[nblk + k]: number of units of step k / where they start
+    uint32_t* d_mid_plan;
+    int32_t* mid_units;
+    int32_t mid_plan_state;  // state: 0 not built, 1 in use, -1 no plan (the two-panel schedule runs)
 };

@@ -369,3 +369,60 @@ def test_refined_sweeps_option_leaves_the_residual_of_substitution():
         assert res["plain"][n] < 1e-11 and res["inv_panel"][n] < 1e-11  # (all of them solve the system)
         assert res["refined"][n] <= 4e-16 * int(n)                         # backward stable: the residual of substitution
         assert res["refined"][n] <= res["plain"][n] * 1.5
+
+
+def test_mid_size_schedules_factor_the_same_matrix():
+    """chol_factor_enqueue's mid-size path (n <= 10 240) has three schedules of the trailing update: planned visits
+    (default, mid_plan.inc), two panels every second step (MADQP_CHOL_MID_LAZY=0) and every panel at once
+    (+ MADQP_CHOL_MID_TWO=0; + MADQP_CHOL_MID_DSYRK=0: the diagonal tile by the GEMM path).  All must give LAPACK's
+    factor up to rounding -- orders with a ragged last block and a single trailing block -- and, since every tile
+    receives its panels in ascending order whatever the schedule, the SAME bits: the factor does not depend on the plan
+    (hence not on the number of CUs the plan was made for)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import hashlib, json, sys
+        import numpy as np, torch
+        sys.path.insert(0, %r)
+        import madqp_jl_amd as M
+        be = M.HipBackend(0)
+        out = {}
+        for n in (129, 257, 1000, 2500, 5001):
+            rng = np.random.default_rng(n)
+            G = torch.as_tensor(rng.standard_normal((n, n + 8)), device=be.device)
+            K = G @ G.T + n * torch.eye(n, dtype=torch.float64, device=be.device)
+            ld = (n + 127) // 128 * 128
+            Kd = torch.zeros((ld, ld), dtype=torch.float64, device=be.device)
+            Kd[:n, :n] = K
+            h = be.chol_create(n)
+            assert be.chol_factor(h, Kd, ld) == 0
+            Lc = torch.tril(Kd.T[:n, :n])                     # the library's layout is column-major: read it transposed
+            ref = torch.linalg.cholesky(K)
+            err = float((Lc - ref).abs().max() / ref.abs().max())
+            x = torch.as_tensor(rng.standard_normal(n), device=be.device)
+            b = K @ x
+            be.chol_solve(h, b)
+            out[str(n)] = [err, float((b - x).abs().max()), hashlib.sha256(Lc.cpu().numpy().tobytes()).hexdigest()]
+            be.chol_destroy(h)
+        be.close()
+        print(json.dumps(out))
+    ''') % root
+    variants = (("planned", {}), ("two_panels", {"MADQP_CHOL_MID_LAZY": "0"}),
+                ("every_panel", {"MADQP_CHOL_MID_LAZY": "0", "MADQP_CHOL_MID_TWO": "0"}),
+                ("gemm_diagonal", {"MADQP_CHOL_MID_LAZY": "0", "MADQP_CHOL_MID_TWO": "0", "MADQP_CHOL_MID_DSYRK": "0"}))
+    first = None
+    for name, env in variants:
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (name, p.stderr[-2000:])
+        res = json.loads(p.stdout.strip().splitlines()[-1])
+        print(name, {n: v[:2] for n, v in res.items()})
+        for n, (err, dx, digest) in res.items():
+            assert err < 1e-12 and dx < 1e-9, (name, n, err, dx)
+        first = first or res
+        if name != "gemm_diagonal":  # (the GEMM path sums the diagonal tile's products in its own order)
+            assert {n: v[2] for n, v in res.items()} == {n: v[2] for n, v in first.items()}, name

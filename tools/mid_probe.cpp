@@ -24,14 +24,14 @@ int main(int argc, char** argv) {
         (void)hipMemcpy(A, h.data(), sizeof(double) * lda * lda, hipMemcpyHostToDevice);
         int32_t info = -1;
         if (madqp_chol_factor(ch, A, lda, &info)) return 1;
-        static unsigned long long st[64][16];
+        static unsigned long long st[64][24];
         (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(madqp_mid_stamps), sizeof(st));
         if (rep < 2) continue;
         const int nblk = (int)(lda / 128);
         printf("info %d; per step: workgroup 0 [update, to LDS, factor + invert]; workgroup 1 [update, store]\n", info);
         for (int k = 0; k < nblk && k < 64; ++k) {
             auto us = [&](int a, int b) { return (double)(st[k][b] - st[k][a]) * 0.01; };
-            printf("k=%2d  diag %5.1f %5.1f %5.1f | other %5.1f", k, us(0, 1), us(1, 2), us(2, 3), us(8, 9));
+            printf("k=%2d  diag %5.1f %5.1f %5.1f | wg1 %5.1f +%4.1f wg2 %5.1f +%4.1f (starts +%.1f)", k, us(0, 1), us(1, 2), us(2, 3), us(8, 9), us(9, 15), us(16, 17), us(17, 23), us(0, 16));
             if (st[k][4]) printf(" | syrk: operand in LDS +%.1f, products +%.1f, all waves done +%.1f, S written +%.1f", us(0, 4), us(4, 5), us(5, 6), us(6, 1));
             if (k + 1 < nblk) printf(" | next step starts +%.1f after the diagonal workgroup ends", (double)(st[k + 1][0] - st[k][3]) * 0.01);
             printf("\n");
