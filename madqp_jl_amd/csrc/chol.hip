@@ -12,7 +12,9 @@
 //       L_jj = chol(C_jj),  W_jj = L_jj^-1                   one workgroup, block resident in LDS
 //       L[jb+128:n, jb] = C[jb+128:n, jb] * W_jj'            gemm core, K = N = 128        (MFMA)
 // Matrices up to n = 10 240 take a right-looking schedule instead (chol_mid_step_kernel below): two launches per
-// 128-column block, the diagonal block factored inside the launch that updates the trailing tiles.
+// 128-column block, the diagonal block factored inside the launch that updates trailing tiles -- which tiles, with
+// which panels, a plan made once per handle decides (mid_plan.inc: updates are applied when there is room, two
+// panels at a time, no later than due).
 // The inverse diagonal blocks W are kept (two images, 2 x n x 128 doubles) and turn the diagonal
 // solves of the two triangular sweeps into 128 x 128 mat-vecs; each sweep is ONE launch of
 // ticket-ordered workgroups handing the solved blocks on through a sentinel-tagged vector, HBM bound
@@ -1050,9 +1052,13 @@ static int32_t panel_solve_sub16(madqp_ctx* ctx, double* C, int64_t ld, const do
 //                         the workgroup holding tile (k, k) goes on to factor and invert it without leaving the CU:
 //                         the updated tile passes from the accumulators to the LDS image of potf2_inv_body;
 //   panel times inverse   L_ik = C_ik W_k' (the GEMM kernel, as in factor_block).
-// Workgroups have 512 threads and the diagonal kernel's LDS (one per CU).  With more tiles than CUs a workgroup
+// Workgroups have 512 threads and the diagonal kernel's LDS (one per CU).  That is schedule MODE 0 with two = 0, the
+// form of round 3 (still selectable); round 4 applies the SAME tile-panel products at other times: MODE 1 (default)
+// takes the units of a step from a plan (see "which trailing columns a block step visits" further down), MODE 0
+// with two = 1 visits every second tile column with two panels.  Every tile still accumulates its panels in the
+// order 0, 1, .., so the factor has the same bits under all of them.  In MODE 0 with more tiles than CUs a workgroup
 // runs two tiles at once: waves 0-3 and waves 4-7 each work like one workgroup of gemm_tn_f64_kernel on their own
-// half of the LDS, in lockstep (both products have K = 128: both halves execute the same barriers).
+// half of the LDS, in lockstep (equal K: both halves execute the same barriers).
 struct MidArgs {
     double* A;
     int64_t lda, n;
@@ -1640,7 +1646,8 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
         static const bool mid_two = mid_dsyrk && !(getenv("MADQP_CHOL_MID_TWO") && atoi(getenv("MADQP_CHOL_MID_TWO")) == 0);
         // planned visits (mid_plan_build) unless switched off; the two-panel schedule otherwise
         static const bool mid_lazy = mid_dsyrk && !(getenv("MADQP_CHOL_MID_LAZY") && atoi(getenv("MADQP_CHOL_MID_LAZY")) == 0);
-        const bool planned = mid_lazy && mid_plan_build(s, nblk, ctx->gemm_slots / 2 - 1);
+        static const int mid_cap = getenv("MADQP_CHOL_MID_CAP") ? atoi(getenv("MADQP_CHOL_MID_CAP")) : 0;  // (experiments)
+        const bool planned = mid_lazy && mid_plan_build(s, nblk, mid_cap > 0 ? mid_cap : ctx->gemm_slots / 2 - 1);
         for (int32_t k = 0; k < nblk; ++k) {
             if (planned) {
                 hipLaunchKernelGGL(chol_mid_step_kernel<1>, dim3((unsigned)(1 + s->mid_units[k])), dim3(MID_THREADS), 0,
