@@ -51,6 +51,7 @@ struct KArgs {
     int32_t ntiles;
     int32_t fast_ok;  // pointers / leading dimensions allow 16-byte loads
     int32_t xcd_remap;
+    int32_t batch_xcd;  // batch: problems dealt to XCDs whole (see gemm_tn_f64_kernel)
     GemmBatch batch;  // B <= 1: single problem
     // split-K (launches with fewer tiles than resident workgroups): blockIdx.y = split, each split
     // covers kchunk of K and stores its raw 128 x 128 partial into work[(split * ntiles + t)]
@@ -63,7 +64,7 @@ struct KArgs {
 };
 
 // wave-uniform operand offsets of a split-K chunk / of problem blockIdx.y of a batch; false: nothing to do
-__device__ __forceinline__ bool gemm_select(const KArgs& ka, GemmArgs& g) {
+__device__ __forceinline__ bool gemm_select(const KArgs& ka, GemmArgs& g, int64_t b_batch = -1) {
     if (ka.ksplit > 1) {
         const int64_t k0 = (int64_t)blockIdx.y * ka.kchunk;
         g.X += k0 * g.ldx;
@@ -73,7 +74,7 @@ __device__ __forceinline__ bool gemm_select(const KArgs& ka, GemmArgs& g) {
         // (a batch of ONE with a skip list is still a batch: round 3 ignored the list then, and the masked retry rounds of
         // the batched engine re-assembled K over the factor of a problem that had not failed -- unnoticed while the sweeps
         // read only the inverse images and the re-computed panels, fatal once the panel solve reads L_kk itself)
-        const int64_t b = blockIdx.y;
+        const int64_t b = b_batch >= 0 ? b_batch : (int64_t)blockIdx.y;
         if (ka.batch.skip && ka.batch.skip[b] != 0) return false;
         g.X += b * ka.batch.sX;
         g.Y += b * ka.batch.sY;
@@ -194,6 +195,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f64_kernel(KArgs ka) {
         return;
     }
     GemmArgs g = ka.g;
+    if (ka.batch_xcd) {
+        // A batch of small problems (grid = tiles x problems, dispatched tile index first): in launch order the ~10 tiles
+        // of ONE problem land on eight different XCDs and each fetches its two operand blocks from HBM -- 5 MB per
+        // problem where the operand is 1 MB.  Re-deal: XCD x (workgroups equal mod 8) takes problems x, x + 8, ..
+        // whole, their tiles on workgroups that start together, so an operand block is fetched once per XCD.
+        const int T = ka.ntiles;
+        const int lin = (int)blockIdx.y * T + (int)blockIdx.x, slot = lin >> 3;
+        const int64_t b = (int64_t)(slot / T) * 8 + (lin & 7);
+        if (!gemm_select(ka, g, b)) return;
+        gemm_tile(ka, g, slot % T, (int)blockIdx.x, lds);
+        return;
+    }
     if (!gemm_select(ka, g)) return;
     // Tile selection: the table is cut into 8 contiguous chunks, one per XCD (workgroup ids equal
     // mod 8 share an XCD under the observed round-robin dispatch; claiming tiles by the real
@@ -407,6 +420,8 @@ int32_t madqp_gemm_tn(madqp_ctx* ctx, const GemmArgs& a, int prof_cls, const int
     ka.batch = batch ? *batch : GemmBatch{1, 0, 0, 0, 0, 0, nullptr};
     unsigned gy = (unsigned)std::max<int64_t>(1, ka.batch.B);
     ARG_TRY(ctx, gy <= 65535);
+    static const int batch_xcd = getenv("MADQP_GEMM_BATCH_XCD") ? atoi(getenv("MADQP_GEMM_BATCH_XCD")) : 1;
+    ka.batch_xcd = (batch_xcd && batch && !ka.batch.list && ka.batch.B >= 8 && ka.batch.B % 8 == 0) ? 1 : 0;
     // Split-K: a launch with far fewer tiles than resident workgroups leaves most of the chip idle while
     // each tile walks all of K alone (5k-20k matrices, the last panels of a large one).  Cut K into up
     // to 16 chunks of >= 256, one workgroup per (tile, chunk), partials summed in chunk order by a second
