@@ -86,6 +86,13 @@ int32_t madqp_read_results(madqp_ctx* ctx, int count, double* out_host);
 int32_t madqp_q_compl(madqp_ctx* ctx, const madqp_state* st, int affine, double ap, double ad, const double* a8,
                       int slot0);                                                               // 2 slots: sums
 int32_t madqp_q_alpha_max(madqp_ctx* ctx, const madqp_state* st, double tau, int slot0);        // 8 slots
+// the same with a scalar that stays in device memory (mpc.hip, body_fused: no read-back between predictor and corrector)
+int32_t madqp_q_alpha_max_dev(madqp_ctx* ctx, const madqp_state* st, double tau, const double* tau_dev, int slot0);
+int32_t madqp_set_correction_rhs_dev(madqp_ctx* ctx, const madqp_state* st, const double* mu_dev);
+int32_t madqp_set_extra_correction_dev(madqp_ctx* ctx, const madqp_state* st, double alpha_p, double alpha_d, double beta_min,
+                                       double beta_max, const double* mu_dev);
+int32_t madqp_q_mpc_mu(madqp_ctx* ctx, int in, int out, int64_t nb, double mu_min, int step_rule, double step_param);
+int32_t madqp_q_mpc_muc(madqp_ctx* ctx, int in, int mu_curr_slot, int out, int64_t nb);
 int32_t madqp_q_inf(madqp_ctx* ctx, const madqp_state* st, int slot0);                          // 4 slots
 void madqp_inf_from_block(const double* out4, double* out3);
 int32_t madqp_q_norm_inf3(madqp_ctx* ctx, int64_t len, const double* a, const double* b, const double* c,

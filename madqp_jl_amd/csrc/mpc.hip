@@ -8,16 +8,20 @@
 // Blocking read-backs.  The sequential form (body_sequential: every reduction returns its scalar at once) makes about
 // ten per iteration, thirteen to sixteen with Gondzio corrections.  The fused form (body_fused; AdaptiveStep /
 // ConservativeStep, no refinement steps) queues the reductions of a phase in the context's result block and reads the
-// block THREE times per iteration, plus twice per tried Gondzio correction (its complementarity estimate, then the
-// residual norms and step lengths that decide whether it is kept):
-//   (a) after the predictor: factorisation info, residual norms of solve_system!, the four step-length minima,
-//       the affine complementarity sums (whose kernel takes the step lengths from the block, not from the host)
-//       and the complementarity sums  -> sigma, mu on the host, in the arithmetic of the sequential form;
-//   (b) after the corrector: residual norms, step-length minima, |dx|  -> SolveException test BEFORE the iterates move;
+// block TWICE per iteration, plus once per tried Gondzio correction (round 3: three times, plus twice):
+//   (b) after the corrector: factorisation info; residual norms of both solve_system! calls, the predictor's step-length
+//       minima and the complementarity sums, from which a one-thread kernel (mpc_mu_kernel) has formed sigma, mu and
+//       the step rule's tau ON THE DEVICE -- the corrector's right-hand side and step-length kernels read them there --
+//       then the corrector's step-length minima and |dx|  -> SolveException test BEFORE the iterates move; likewise
+//       a Gondzio trial's mu_c (mpc_muc_kernel), so that a trial costs the one read-back that decides whether it
+//       is kept;
 //   (c) after the update: objective sums and the residual norms of the NEXT termination test (madqp_mpc_head then
 //       finds them cached).
-// Same kernels, same host arithmetic, same order on the stream: the iterates are bitwise those of the sequential
-// form (tests/test_gpu_solver.py).  A failed first factorisation (the x100 retries of src/linear_solver.jl:6-17)
+// A read-back is a 28 us round trip, and the launches behind it start from an empty queue -- 3.7 us each from the
+// host against 1.6 us when they are already queued (tools/launch_probe.cpp) -- so each one removed is worth ~0.1 ms at
+// n_x = 5 000.
+// Same kernels, the same arithmetic operation for operation (on the device where the scalar stays there), same order on
+// the stream: the iterates are bitwise those of the sequential form (tests/test_gpu_solver.py).  A failed first factorisation (the x100 retries of src/linear_solver.jl:6-17)
 // sends the rest of that iteration down the sequential form.
 #include <cmath>
 #include <cstdlib>
@@ -338,7 +342,7 @@ int32_t body_after_factorization(madqp_mpc* s, madqp_mpc_info* info_host) {
     double sigma = 1.0;
     if (s->st.nlb + s->st.nub > 0) {
         const double t = mu_affine / mu_curr;
-        sigma = std::min(std::max(std::pow(t, 3.0), 1e-6), 10.0);  // pow: same libm call as the Python driver
+        sigma = std::min(std::max(t * t * t, 1e-6), 10.0);  // t^3 as Julia's literal power forms it; the Python driver and mpc_mu_kernel too
     }
     s->mu = std::max(s->opt.mu_min, sigma * mu_curr);
     TRY(madqp_set_correction_rhs(ctx, &s->st, s->mu));  // :307
@@ -384,7 +388,7 @@ int32_t residual_verdict(madqp_mpc* s, const double* nrm) {  // src/linear_solve
 }
 inline double min_like_host(double a, double b) { return std::min(a, b); }  // fraction_to_boundary's combination
 
-// The same iteration with three blocking read-backs (see the head of this file).
+// The same iteration with two blocking read-backs (see the head of this file).
 int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
     madqp_ctx* ctx = s->ctx;
     const int64_t nb = s->st.nlb + s->st.nub;
@@ -401,9 +405,26 @@ int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
     TRY(madqp_q_compl(ctx, &s->st, 1, 0.0, 0.0, ctx->d_res + 3, 11));            // :296, step lengths from the block
     TRY(madqp_get_correction(ctx, &s->st));                                      // :297
     TRY(madqp_q_compl(ctx, &s->st, 0, 0.0, 0.0, nullptr, 13));
-    TRY(madqp_read_results(ctx, 16, r));
+    // update_barrier! on the device: mu, the step rule's tau and mu_curr into the block (SL_MU ..) -- the corrector is
+    // queued behind the predictor without a read-back in between (round 4: a read-back costs 28 us and leaves the
+    // queue empty: the ~35 launches behind it are then issued at the host's 3.7 us each instead of the 1.6 us the
+    // GPU takes them at from a filled queue, tools/launch_probe.cpp)
+    const int SL_MU = 32, SL_TAU = 33, SL_MUCURR = 34, SL_NRM_B = 35, SL_ALPHA_B = 38, SL_DNORM_B = 46, SL_ALPHA_GZ = 49,
+              SL_MUC = 58;
+    TRY(madqp_q_mpc_mu(ctx, 11, SL_MU, nb, s->opt.mu_min, s->opt.step_rule, s->opt.step_param));
+    // (b) corrector.  The step rule's minima and |dx| are queued behind every direction that may turn out to be the
+    // final one, so that the Gondzio loop below ends without a read-back of its own.
+    TRY(madqp_set_correction_rhs_dev(ctx, &s->st, ctx->d_res + SL_MU));  // :307
+    TRY(solve_system_queue(s, SL_NRM_B));
+    const bool gz = s->opt.max_ncorr > 0;
+    const double gz_tau = 0.995, gz_delta = 0.1, gz_bmin = 0.1, gz_bmax = 10.0;  // src/solver.jl:200-251
+    TRY(madqp_q_alpha_max_dev(ctx, &s->st, 0.0, ctx->d_res + SL_TAU, SL_ALPHA_B));
+    TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, SL_DNORM_B));  // print_iter, src/structure.jl:190
+    if (gz) TRY(madqp_q_alpha_max(ctx, &s->st, gz_tau, SL_ALPHA_GZ));
+    double rb[MADQP_RESULT_SLOTS];
+    TRY(madqp_read_results(ctx, SL_ALPHA_GZ + 8, rb));
     s->n_readbacks += 1;
-    s->last_info = (int32_t)r[15];
+    s->last_info = (int32_t)rb[15];
     TRY(madqp_kkt_factor_result(s->kkt, s->last_info));
     if (s->last_info != 0) {  // src/linear_solver.jl:6-17: what was queued behind the failed factorisation is void
         s->del_w *= 100.0;
@@ -411,49 +432,27 @@ int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
         TRY(factorize_regularized_system(s, 1));
         return body_after_factorization(s, info_host);
     }
-    TRY(residual_verdict(s, r));
-    const double mu_affine = nb ? (r[11] + r[12]) / (double)nb : 0.0;
-    const double mu_curr = nb ? (r[13] + r[14]) / (double)nb : 0.0;
-    double sigma = 1.0;
-    if (nb > 0) {
-        const double t = mu_affine / mu_curr;
-        sigma = std::min(std::max(std::pow(t, 3.0), 1e-6), 10.0);
-    }
-    s->mu = std::max(s->opt.mu_min, sigma * mu_curr);
-    // (b) corrector.  The step rule's minima and |dx| are queued behind every direction that may turn out to be the
-    // final one, so that the Gondzio loop below ends without a read-back of its own.
-    TRY(madqp_set_correction_rhs(ctx, &s->st, s->mu));  // :307
-    TRY(solve_system_queue(s, 0));
-    const double tau = (s->opt.step_rule == 0) ? s->opt.step_param : std::max(1.0 - s->mu, s->opt.step_param);
-    const bool gz = s->opt.max_ncorr > 0;
-    const double gz_tau = 0.995, gz_delta = 0.1, gz_bmin = 0.1, gz_bmax = 10.0;  // src/solver.jl:200-251
-    TRY(madqp_q_alpha_max(ctx, &s->st, tau, 3));
-    TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, 11));  // print_iter, src/structure.jl:190
-    if (gz) TRY(madqp_q_alpha_max(ctx, &s->st, gz_tau, 14));
-    double rb[32];
-    TRY(madqp_read_results(ctx, gz ? 22 : 14, rb));
-    s->n_readbacks += 1;
-    TRY(residual_verdict(s, rb));
-    s->alpha_p = min_like_host(rb[3], rb[5]);
-    s->alpha_d = min_like_host(rb[7], rb[9]);
-    s->dnorm = rb[11];
-    if (gz) {  // gondzio(), two read-backs per tried correction instead of three + the step rule's afterwards
+    TRY(residual_verdict(s, rb));             // the predictor's solve
+    s->mu = rb[SL_MU];
+    TRY(residual_verdict(s, rb + SL_NRM_B));  // the corrector's
+    s->alpha_p = min_like_host(rb[SL_ALPHA_B + 0], rb[SL_ALPHA_B + 2]);
+    s->alpha_d = min_like_host(rb[SL_ALPHA_B + 4], rb[SL_ALPHA_B + 6]);
+    s->dnorm = rb[SL_DNORM_B];
+    if (gz) {  // gondzio(): ONE read-back per tried correction (mu_c stays on the device), none for the step rule afterwards
         const int64_t len = ntot(s->st);
-        double g_ap = min_like_host(rb[14], rb[16]), g_ad = min_like_host(rb[18], rb[20]);
+        double g_ap = min_like_host(rb[SL_ALPHA_GZ + 0], rb[SL_ALPHA_GZ + 2]);
+        double g_ad = min_like_host(rb[SL_ALPHA_GZ + 4], rb[SL_ALPHA_GZ + 6]);
         for (int c = 0; c < s->opt.max_ncorr; ++c) {
             const double ta_p = std::min(g_ap + gz_delta, 1.0), ta_d = std::min(g_ad + gz_delta, 1.0);
             TRY(madqp_q_compl(ctx, &s->st, 1, ta_p, ta_d, nullptr, 0));
-            TRY(madqp_read_results(ctx, 2, rb));
-            s->n_readbacks += 1;
-            const double ga = nb ? (rb[0] + rb[1]) / (double)nb : 0.0;
-            const double mu_c = (ga / mu_curr) * (ga / mu_curr) * ga;
-            TRY(madqp_set_extra_correction(ctx, &s->st, ta_p, ta_d, gz_bmin, gz_bmax, mu_c));
-            TRY(madqp_set_correction_rhs(ctx, &s->st, mu_c));
+            TRY(madqp_q_mpc_muc(ctx, 0, SL_MUCURR, SL_MUC, nb));
+            TRY(madqp_set_extra_correction_dev(ctx, &s->st, ta_p, ta_d, gz_bmin, gz_bmax, ctx->d_res + SL_MUC));
+            TRY(madqp_set_correction_rhs_dev(ctx, &s->st, ctx->d_res + SL_MUC));
             TRY(madqp_copy(ctx, len, s->st.d, s->w2));
             TRY(solve_system_queue(s, 0));
             TRY(madqp_q_alpha_max(ctx, &s->st, gz_tau, 3));
-            TRY(madqp_q_alpha_max(ctx, &s->st, tau, 14));                          // in case this direction is kept
-            TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, 22));  // and is the last one
+            TRY(madqp_q_alpha_max_dev(ctx, &s->st, 0.0, ctx->d_res + SL_TAU, 14));  // in case this direction is kept
+            TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, 22));    // and is the last one
             TRY(madqp_read_results(ctx, 25, rb));
             s->n_readbacks += 1;
             TRY(residual_verdict(s, rb));

@@ -71,11 +71,17 @@ extern "C" int32_t madqp_set_aug_diagonal_reg(madqp_ctx* ctx, const madqp_state*
     return MADQP_OK;
 }
 
-static int32_t rhs_launch(madqp_ctx* ctx, const madqp_state* st, int mode, double mu) {
+static int32_t rhs_launch(madqp_ctx* ctx, const madqp_state* st, int mode, double mu, const double* mu_dev = nullptr) {
     CHECK_STATE();
     ProfScope ps(ctx, MADQP_PROF_VEC);
-    LAUNCH(rhs_kernel, max4(st->n, st->m, st->nlb, st->nub), *st, mode, mu);
+    LAUNCH(rhs_kernel, max4(st->n, st->m, st->nlb, st->nub), *st, mode, mu, mu_dev);
     return MADQP_OK;
+}
+// set_correction_rhs! with mu taken from device memory (mpc.hip, body_fused)
+int32_t madqp_set_correction_rhs_dev(madqp_ctx* ctx, const madqp_state* st, const double* mu_dev) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, mu_dev != nullptr);
+    return rhs_launch(ctx, st, 1, 0.0, mu_dev);
 }
 extern "C" int32_t madqp_set_initial_primal_rhs(madqp_ctx* ctx, const madqp_state* st) {
     return rhs_launch(ctx, st, 2, 0.0);
@@ -103,7 +109,63 @@ extern "C" int32_t madqp_set_extra_correction(madqp_ctx* ctx, const madqp_state*
     CHECK_STATE();
     ProfScope ps(ctx, MADQP_PROF_VEC);
     LAUNCH(extra_correction_kernel, std::max(st->nlb, st->nub), *st, alpha_p, alpha_d,
-           beta_min * mu, beta_max * mu);
+           beta_min * mu, beta_max * mu, nullptr);
+    return MADQP_OK;
+}
+// the same with mu in device memory: the kernel forms beta_min * mu, beta_max * mu
+int32_t madqp_set_extra_correction_dev(madqp_ctx* ctx, const madqp_state* st, double alpha_p, double alpha_d,
+                                       double beta_min, double beta_max, const double* mu_dev) {
+    CHECK_STATE();
+    ARG_TRY(ctx, mu_dev != nullptr);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    LAUNCH(extra_correction_kernel, std::max(st->nlb, st->nub), *st, alpha_p, alpha_d, beta_min, beta_max, mu_dev);
+    return MADQP_OK;
+}
+
+// ---- scalars of the iteration that never visit the host (mpc.hip, body_fused) -------------------------------------------
+// update_barrier!(Mehrotra) (src/kernels.jl:226-236) from the four complementarity sums of the result block:
+// res[out] = mu, res[out+1] = tau of the step rule, res[out+2] = mu_curr -- the arithmetic of the host form, operation
+// for operation ((mu_aff / mu_curr)^3 as t*t*t, which is what Julia's literal power is)
+__global__ void mpc_mu_kernel(double* __restrict__ res, int in, int out, double nb, double mu_min, int step_rule,
+                              double step_param) {
+    if (threadIdx.x || blockIdx.x) return;
+    const double mu_affine = nb > 0.0 ? (res[in] + res[in + 1]) / nb : 0.0;
+    const double mu_curr = nb > 0.0 ? (res[in + 2] + res[in + 3]) / nb : 0.0;
+    double sigma = 1.0;
+    if (nb > 0.0) {
+        const double t = mu_affine / mu_curr;
+        sigma = fmin(fmax(t * t * t, 1e-6), 10.0);
+    }
+    const double sm = sigma * mu_curr;
+    const double mu = (mu_min > sm) ? mu_min : sm;  // std::max(mu_min, sigma * mu_curr)
+    res[out] = mu;
+    const double om = 1.0 - mu;
+    res[out + 1] = (step_rule == 0) ? step_param : ((om > step_param) ? om : step_param);  // std::max(1 - mu, step_param)
+    res[out + 2] = mu_curr;
+}
+// gondzio_correction_direction! (src/solver.jl:200-251): mu_c = (ga / mu_curr)^2 ga from the two sums at res[in]
+__global__ void mpc_muc_kernel(double* __restrict__ res, int in, int mu_curr_slot, int out, double nb) {
+    if (threadIdx.x || blockIdx.x) return;
+    const double ga = nb > 0.0 ? (res[in] + res[in + 1]) / nb : 0.0;
+    const double mu_curr = res[mu_curr_slot];
+    res[out] = (ga / mu_curr) * (ga / mu_curr) * ga;
+}
+int32_t madqp_q_mpc_mu(madqp_ctx* ctx, int in, int out, int64_t nb, double mu_min, int step_rule, double step_param) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, in >= 0 && in + 4 <= MADQP_FAULT_SLOT && out >= 0 && out + 3 <= MADQP_FAULT_SLOT);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    hipLaunchKernelGGL(mpc_mu_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_res, in, out, (double)nb, mu_min, step_rule,
+                       step_param);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
+int32_t madqp_q_mpc_muc(madqp_ctx* ctx, int in, int mu_curr_slot, int out, int64_t nb) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, in >= 0 && in + 2 <= MADQP_FAULT_SLOT && out >= 0 && out < MADQP_FAULT_SLOT && mu_curr_slot >= 0 &&
+                     mu_curr_slot < MADQP_FAULT_SLOT);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    hipLaunchKernelGGL(mpc_muc_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_res, in, mu_curr_slot, out, (double)nb);
+    LAUNCH_CHECK(ctx);
     return MADQP_OK;
 }
 
@@ -160,7 +222,12 @@ __global__ void alpha_none_kernel(double* __restrict__ res) {  // no bounds: alp
     }
 }
 }  // namespace
+int32_t madqp_q_alpha_max_dev(madqp_ctx* ctx, const madqp_state* st, double tau, const double* tau_dev, int slot0);
 int32_t madqp_q_alpha_max(madqp_ctx* ctx, const madqp_state* st, double tau, int slot0) {
+    return madqp_q_alpha_max_dev(ctx, st, tau, nullptr, slot0);
+}
+// tau_dev != nullptr: tau is read from device memory
+int32_t madqp_q_alpha_max_dev(madqp_ctx* ctx, const madqp_state* st, double tau, const double* tau_dev, int slot0) {
     CHECK_STATE();
     const int64_t L = std::max(st->nlb, st->nub);
     ProfScope ps(ctx, MADQP_PROF_VEC);
@@ -170,7 +237,7 @@ int32_t madqp_q_alpha_max(madqp_ctx* ctx, const madqp_state* st, double tau, int
         return MADQP_OK;
     }
     const int nb = grid_for(L);
-    hipLaunchKernelGGL(alpha_max_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, *st, tau, ctx->d_part);
+    hipLaunchKernelGGL(alpha_max_kernel, dim3(nb), dim3(TPB), 0, ctx->stream, *st, tau, ctx->d_part, tau_dev);
     LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(alpha_max_final_kernel, dim3(1), dim3(TPB), 0, ctx->stream, ctx->d_part, nb,
                        ctx->d_res + slot0);

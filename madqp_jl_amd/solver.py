@@ -233,7 +233,11 @@ class MPCSolver:
     def update_barrier(self, mu_affine):  # kernels.jl:226-236 (field-order quirk: SURVEY 0c)
         has_inequalities = (self.nlb + self.nub) > 0
         mu_curr = self.be.get_complementarity_measure(self.st)
-        sigma = min(max((mu_affine / mu_curr) ** 3, 1e-6), 10.0) if has_inequalities else 1.0
+        if has_inequalities:
+            t = mu_affine / mu_curr
+            sigma = min(max(t * t * t, 1e-6), 10.0)  # t^3 as Julia's literal power forms it (and csrc/mpc.hip, mpc_mu_kernel)
+        else:
+            sigma = 1.0
         self.mu = max(self.opt.mu_min, sigma * mu_curr)
         return mu_curr
 

@@ -113,6 +113,12 @@ int main() {
         run_panel(ctx, 50000, 30720, 1920, 0);
         run_panel(ctx, 49920, 40960, 2048, 0);
         run_panel(ctx, 50000, 40960, 2048, 0);
+    } else if (getenv("PROBE_MID")) {  // the assembly of the mid sizes (configs[1]: n = 5000, K = 2000) beside a long-K one
+        run(ctx, 5000, 2000, true, true);
+        run(ctx, 5120, 2048, true, true);
+        run(ctx, 5000, 20000, true, true);
+        run(ctx, 3000, 1200, true, true);
+        run(ctx, 8000, 3200, true, true);
     } else if (getenv("PROBE_ONE")) {
         const char* e = getenv("PROBE_N");
         run(ctx, e ? atol(e) : 24576, 20480, true, getenv("PROBE_NOBASE") ? false : true);
