@@ -1,4 +1,5 @@
-"""Third model: constant budget of R rounds per step, smallest R whose plan never needs more than qmax panels in a visit."""
+"""Cost model of the planned trailing updates of the mid-size factorisation (design aid for madqp_jl_amd/csrc/mid_plan.inc, never
+part of the product): constant budget of R rounds per step, smallest R whose plan never needs more than qmax panels in a visit."""
 import sys
 
 
