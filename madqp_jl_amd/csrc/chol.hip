@@ -69,6 +69,17 @@ __device__ __forceinline__ double fast_rsqrt(double a) {
     return h + h;
 }
 
+// the 16 x 16 sub-block at (b, b) of S, both triangles from the stored lower one, in the accumulator layout
+__device__ __forceinline__ double4_t diag16_load(const double* __restrict__ S, int b, int lane) {
+    const int lo = lane & 15, hi = lane >> 4;
+    double4_t A;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int row = hi + 4 * v;
+        A[v] = (row >= lo) ? S[(b + lo) * LDS_LD + b + row] : S[(b + row) * LDS_LD + b + lo];
+    }
+    return A;
+}
 // One wave: Cholesky of the 16 x 16 sub-block at (b, b) of S and the inverse of its factor, in four RANK-4 steps on the
 // MFMA unit.  The (symmetric) sub-block and W live in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l,
 // register v: row (l>>4) + 4v, column l&15), so the four rows 4p .. 4p+3 of the block are ONE register (A[p]: lane
@@ -83,16 +94,13 @@ __device__ __forceinline__ double fast_rsqrt(double a) {
 // later row.  Every update is one fused multiply-add, in the order of the pivots; W = L^-1 follows from the same steps
 // applied to the identity (W[k,:] *= 1/l_kk, W[i,:] -= l_ik W[k,:], i > k).  Writes L (lower) back to S and W to
 // Wd[r*WD_LD + c] (zero above the diagonal).
-__device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int b, double* __restrict__ Wd,
+// A: the symmetric sub-block in the accumulator layout (diag16_load, or the accumulators of the update that completed it)
+__device__ __forceinline__ void diag16_factor_invert(double4_t A, double* __restrict__ S, int b, double* __restrict__ Wd,
                                                         int32_t* __restrict__ info, int32_t col0, int lane) {
     const int lo = lane & 15, hi = lane >> 4;
-    double4_t A, W;
+    double4_t W;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int row = hi + 4 * v;
-        A[v] = (row >= lo) ? S[(b + lo) * LDS_LD + b + row] : S[(b + row) * LDS_LD + b + lo];
-        W[v] = (row == lo) ? 1.0 : 0.0;
-    }
+    for (int v = 0; v < 4; ++v) W[v] = (hi + 4 * v == lo) ? 1.0 : 0.0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int k0 = 4 * p;
@@ -154,7 +162,7 @@ __device__ __forceinline__ void diag16_factor_invert(double* __restrict__ S, int
 __device__ unsigned long long madqp_potf2_stamps[64];  // diagnostic build only (tools/potf2_probe.cpp)
 #define P2_STAMP(i)                                                                    \
     do {                                                                               \
-        if (threadIdx.x == 0) madqp_potf2_stamps[i] = __builtin_amdgcn_s_memrealtime(); \
+        if (threadIdx.x == 0 && MODE != 2) madqp_potf2_stamps[i] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define P2_STAMP(i)
@@ -329,7 +337,7 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
         for (int v = 0; v < 4; ++v) S[(SB * I + hi + 4 * v) * LDS_LD + SB * Jp + lo] = -R[v];
     };
     constexpr int NWV = NT / 64, NH = NWV - 1;  // waves; helper waves 1..NH
-    if (MODE != 2 && wave == 0) diag16_factor_invert(S, 0, Wd, info, col0, lane);
+    if (MODE != 2 && wave == 0) diag16_factor_invert(diag16_load(S, 0, lane), S, 0, Wd, info, col0, lane);
     __syncthreads();
     P2_STAMP(2);
     for (int J = 0; J < NSB; ++J) {
@@ -362,7 +370,9 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
             if (wave == 0) {
                 if (MODE != 2) {
                     trailing_tile(J, J + 1, J + 1);
-                    diag16_factor_invert(S, b + SB, WdJ + SB * WD_LD, info, col0, lane);
+                    // (keeping this update in registers as the input of the pivot chain, instead of the round trip through
+                    // S, changed nothing: 2.12-2.20 us per step either way)
+                    diag16_factor_invert(diag16_load(S, b + SB, lane), S, b + SB, WdJ + SB * WD_LD, info, col0, lane);
                 }
             } else if (P2_QUIET < 0 || (wave & 3) != 0) {
                 // (waves 4, 8, .. share their SIMD with wave 0 and sit this phase out: the fp64 MFMAs of a helper
@@ -378,22 +388,25 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
                     else
                         trailing_tile(J, (e >> 3) & 7, e & 7);
                 }
+                // the 16 columns of L that step J completed go to global memory now, beside wave 0's pivot chain
+                // (round 4: as one pass after the last step the store of the factor was 1.5 us at the END of the chain)
+                if (MODE != 2) {
+                    for (int c = b + hr; c < b + SB && c < nb; c += NHE) {
+                        const double* sc = S + c * LDS_LD;
+                        double* gc = A + (int64_t)c * lda;
+                        if (lane >= c && lane < nb) gc[lane] = sc[lane];
+                        if (lane + 64 >= c && lane + 64 < nb) gc[lane + 64] = sc[lane + 64];
+                    }
+                }
             }
         }
         __syncthreads();
         P2_STAMP(4 + 3 * J);
     }
-    // factor -> global (lower triangle only): row r = tid & 127, columns (tid >> 7) + CG*i
+    // the last 16 columns of the factor -> global (the others went out step by step)
     if (MODE != 2) {
-        constexpr int CG = NT / NB;
-        const int r = tid & (NB - 1), c0 = tid >> 7;
-        if (r < nb) {
-#pragma unroll 8
-            for (int i = 0; i < NB / CG; ++i) {
-                const int c = c0 + CG * i;
-                if (c <= r) A[r + (int64_t)c * lda] = S[c * LDS_LD + r];
-            }
-        }
+        const int r = (NSB - 1) * SB + (tid & 15), c = (NSB - 1) * SB + (tid >> 4);
+        if (tid < SB * SB && c <= r && r < nb) A[r + (int64_t)c * lda] = S[c * LDS_LD + r];
     }
     P2_STAMP(26);
     P2_STAMP(27);

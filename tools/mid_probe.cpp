@@ -37,5 +37,18 @@ int main(int argc, char** argv) {
             printf("\n");
         }
     }
+#ifdef MADQP_POTF2_STAMPS
+    {   // the phases of the diagonal kernel body inside the LAST block step (the stamps of every step land in the same slots)
+        unsigned long long st[64];
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(madqp_potf2_stamps), sizeof(st));
+        auto us = [&](int a, int b) { return (double)(st[b] - st[a]) * 0.01; };
+        printf("last step, diagonal body: total %.1f us | to LDS %.1f | first 16x16 %.2f | J-steps %.1f | store L %.1f | store W %.1f\n",
+               us(0, 28), us(0, 1), us(1, 2), us(2, 25), us(25, 26), us(27, 28));
+        for (int J = 0; J < 8; ++J) {
+            const int prev = (J == 0) ? 2 : 4 + 3 * (J - 1);
+            printf("   J=%d panel %.2f  trailing || next 16x16 %.2f\n", J, us(prev, 3 + 3 * J), us(3 + 3 * J, 4 + 3 * J));
+        }
+    }
+#endif
     return 0;
 }
