@@ -566,7 +566,11 @@ class MPCSolver:
     def update_barrier(self, mu_affine):  # kernels.jl:226-236 (+ field-order quirk)
         has_inequalities = (self.nlb + self.nub) > 0
         mu_curr = self.get_complementarity_measure()
-        sigma = min(max((mu_affine / mu_curr) ** 3, 1e-6), 10.0) if has_inequalities else 1.0
+        if has_inequalities:
+            t = mu_affine / mu_curr
+            sigma = min(max(t * t * t, 1e-6), 10.0)  # (mu_affine / mu_curr)^3: Julia lowers a literal power of 3 to x*x*x
+        else:
+            sigma = 1.0
         self.mu = max(self.opt.mu_min, sigma * mu_curr)
         return mu_curr
 
