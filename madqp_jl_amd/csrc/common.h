@@ -10,7 +10,7 @@
 
 #include "../../include/madqp.h"
 
-#define MADQP_RESULT_SLOTS 64
+#define MADQP_RESULT_SLOTS 128
 // last slot of the result block: device-side fault word (non-zero: a triangular sweep's hand-off timed out);
 // it rides along with every synchronising scalar read-back (madqp_read_results) and turns into MADQP_ERR_HIP
 #define MADQP_FAULT_SLOT (MADQP_RESULT_SLOTS - 1)
@@ -89,8 +89,12 @@ int32_t madqp_q_alpha_max(madqp_ctx* ctx, const madqp_state* st, double tau, int
 // the same with a scalar that stays in device memory (mpc.hip, body_fused: no read-back between predictor and corrector)
 int32_t madqp_q_alpha_max_dev(madqp_ctx* ctx, const madqp_state* st, double tau, const double* tau_dev, int slot0);
 int32_t madqp_set_correction_rhs_dev(madqp_ctx* ctx, const madqp_state* st, const double* mu_dev);
+// a8 != nullptr: the step lengths are min(a8[0], a8[2]), min(a8[4], a8[6]) read on the device (as madqp_q_compl's a8)
 int32_t madqp_set_extra_correction_dev(madqp_ctx* ctx, const madqp_state* st, double alpha_p, double alpha_d, double beta_min,
-                                       double beta_max, const double* mu_dev);
+                                       double beta_max, const double* mu_dev, const double* a8 = nullptr);
+// Gondzio's trial step lengths min(alpha + delta, 1) from the 8-slot step-length block at `in`, written in the pattern
+// madqp_q_compl / madqp_set_extra_correction_dev read (slots out+0, +2: primal; out+4, +6: dual)
+int32_t madqp_q_mpc_trial_alpha(madqp_ctx* ctx, int in, int out, double delta);
 int32_t madqp_q_mpc_mu(madqp_ctx* ctx, int in, int out, int64_t nb, double mu_min, int step_rule, double step_param);
 int32_t madqp_q_mpc_muc(madqp_ctx* ctx, int in, int mu_curr_slot, int out, int64_t nb);
 int32_t madqp_q_inf(madqp_ctx* ctx, const madqp_state* st, int slot0);                          // 4 slots

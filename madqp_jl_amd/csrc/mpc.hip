@@ -8,13 +8,15 @@
 // Blocking read-backs.  The sequential form (body_sequential: every reduction returns its scalar at once) makes about
 // ten per iteration, thirteen to sixteen with Gondzio corrections.  The fused form (body_fused; AdaptiveStep /
 // ConservativeStep, no refinement steps) queues the reductions of a phase in the context's result block and reads the
-// block TWICE per iteration, plus once per tried Gondzio correction (round 3: three times, plus twice):
+// block TWICE per iteration, plus once per tried Gondzio correction beyond the first (round 3: three times, plus twice
+// per trial):
 //   (b) after the corrector: factorisation info; residual norms of both solve_system! calls, the predictor's step-length
 //       minima and the complementarity sums, from which a one-thread kernel (mpc_mu_kernel) has formed sigma, mu and
 //       the step rule's tau ON THE DEVICE -- the corrector's right-hand side and step-length kernels read them there --
 //       then the corrector's step-length minima and |dx|  -> SolveException test BEFORE the iterates move; likewise
-//       a Gondzio trial's mu_c (mpc_muc_kernel), so that a trial costs the one read-back that decides whether it
-//       is kept;
+//       a Gondzio trial's mu_c (mpc_muc_kernel) and, for the FIRST trial, its step lengths min(alpha + delta, 1)
+//       (mpc_trial_alpha_kernel): that trial is queued behind the corrector and decided from the same read-back; a
+//       further trial costs the one read-back that decides whether it is kept;
 //   (c) after the update: objective sums and the residual norms of the NEXT termination test (madqp_mpc_head then
 //       finds them cached).
 // A read-back is a 28 us round trip, and the launches behind it start from an empty queue -- 3.7 us each from the
@@ -420,9 +422,25 @@ int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
     const double gz_tau = 0.995, gz_delta = 0.1, gz_bmin = 0.1, gz_bmax = 10.0;  // src/solver.jl:200-251
     TRY(madqp_q_alpha_max_dev(ctx, &s->st, 0.0, ctx->d_res + SL_TAU, SL_ALPHA_B));
     TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, SL_DNORM_B));  // print_iter, src/structure.jl:190
-    if (gz) TRY(madqp_q_alpha_max(ctx, &s->st, gz_tau, SL_ALPHA_GZ));
+    const int64_t len = ntot(s->st);
+    // gondzio(), first trial: queued behind the corrector, its step lengths min(alpha + delta, 1) and its mu_c formed on
+    // the device from the block -- the read-back that follows serves the corrector AND the trial
+    const int SL_TA = 64, SL_T_COMPL = 72, SL_T_NRM = 74, SL_T_AGZ = 77, SL_T_ATAU = 85, SL_T_DN = 93;
+    if (gz) {
+        TRY(madqp_q_alpha_max(ctx, &s->st, gz_tau, SL_ALPHA_GZ));
+        TRY(madqp_q_mpc_trial_alpha(ctx, SL_ALPHA_GZ, SL_TA, gz_delta));
+        TRY(madqp_q_compl(ctx, &s->st, 1, 0.0, 0.0, ctx->d_res + SL_TA, SL_T_COMPL));
+        TRY(madqp_q_mpc_muc(ctx, SL_T_COMPL, SL_MUCURR, SL_MUC, nb));
+        TRY(madqp_set_extra_correction_dev(ctx, &s->st, 0.0, 0.0, gz_bmin, gz_bmax, ctx->d_res + SL_MUC, ctx->d_res + SL_TA));
+        TRY(madqp_set_correction_rhs_dev(ctx, &s->st, ctx->d_res + SL_MUC));
+        TRY(madqp_copy(ctx, len, s->st.d, s->w2));
+        TRY(solve_system_queue(s, SL_T_NRM));
+        TRY(madqp_q_alpha_max(ctx, &s->st, gz_tau, SL_T_AGZ));
+        TRY(madqp_q_alpha_max_dev(ctx, &s->st, 0.0, ctx->d_res + SL_TAU, SL_T_ATAU));  // in case this direction is kept
+        TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, SL_T_DN));      // and is the last one
+    }
     double rb[MADQP_RESULT_SLOTS];
-    TRY(madqp_read_results(ctx, SL_ALPHA_GZ + 8, rb));
+    TRY(madqp_read_results(ctx, gz ? SL_T_DN + 3 : SL_DNORM_B + 3, rb));
     s->n_readbacks += 1;
     s->last_info = (int32_t)rb[15];
     TRY(madqp_kkt_factor_result(s->kkt, s->last_info));
@@ -438,34 +456,38 @@ int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
     s->alpha_p = min_like_host(rb[SL_ALPHA_B + 0], rb[SL_ALPHA_B + 2]);
     s->alpha_d = min_like_host(rb[SL_ALPHA_B + 4], rb[SL_ALPHA_B + 6]);
     s->dnorm = rb[SL_DNORM_B];
-    if (gz) {  // gondzio(): ONE read-back per tried correction (mu_c stays on the device), none for the step rule afterwards
-        const int64_t len = ntot(s->st);
+    if (gz) {  // the first trial is in the block; a further one (while the last was kept) costs a read-back of its own
         double g_ap = min_like_host(rb[SL_ALPHA_GZ + 0], rb[SL_ALPHA_GZ + 2]);
         double g_ad = min_like_host(rb[SL_ALPHA_GZ + 4], rb[SL_ALPHA_GZ + 6]);
+        const double* tb = rb + SL_T_NRM;  // norms [0..2], steps at gz_tau [3..10], steps at tau [11..18], |dx| [19]
+        double tr[32];
         for (int c = 0; c < s->opt.max_ncorr; ++c) {
-            const double ta_p = std::min(g_ap + gz_delta, 1.0), ta_d = std::min(g_ad + gz_delta, 1.0);
-            TRY(madqp_q_compl(ctx, &s->st, 1, ta_p, ta_d, nullptr, 0));
-            TRY(madqp_q_mpc_muc(ctx, 0, SL_MUCURR, SL_MUC, nb));
-            TRY(madqp_set_extra_correction_dev(ctx, &s->st, ta_p, ta_d, gz_bmin, gz_bmax, ctx->d_res + SL_MUC));
-            TRY(madqp_set_correction_rhs_dev(ctx, &s->st, ctx->d_res + SL_MUC));
-            TRY(madqp_copy(ctx, len, s->st.d, s->w2));
-            TRY(solve_system_queue(s, 0));
-            TRY(madqp_q_alpha_max(ctx, &s->st, gz_tau, 3));
-            TRY(madqp_q_alpha_max_dev(ctx, &s->st, 0.0, ctx->d_res + SL_TAU, 14));  // in case this direction is kept
-            TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, 22));    // and is the last one
-            TRY(madqp_read_results(ctx, 25, rb));
-            s->n_readbacks += 1;
-            TRY(residual_verdict(s, rb));
-            const double ha_p = min_like_host(rb[3], rb[5]), ha_d = min_like_host(rb[7], rb[9]);
+            if (c > 0) {
+                const double ta_p = std::min(g_ap + gz_delta, 1.0), ta_d = std::min(g_ad + gz_delta, 1.0);
+                TRY(madqp_q_compl(ctx, &s->st, 1, ta_p, ta_d, nullptr, 0));
+                TRY(madqp_q_mpc_muc(ctx, 0, SL_MUCURR, SL_MUC, nb));
+                TRY(madqp_set_extra_correction_dev(ctx, &s->st, ta_p, ta_d, gz_bmin, gz_bmax, ctx->d_res + SL_MUC));
+                TRY(madqp_set_correction_rhs_dev(ctx, &s->st, ctx->d_res + SL_MUC));
+                TRY(madqp_copy(ctx, len, s->st.d, s->w2));
+                TRY(solve_system_queue(s, 0));
+                TRY(madqp_q_alpha_max(ctx, &s->st, gz_tau, 3));
+                TRY(madqp_q_alpha_max_dev(ctx, &s->st, 0.0, ctx->d_res + SL_TAU, 11));
+                TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, 19));
+                TRY(madqp_read_results(ctx, 22, tr));
+                s->n_readbacks += 1;
+                tb = tr;
+            }
+            TRY(residual_verdict(s, tb));
+            const double ha_p = min_like_host(tb[3], tb[5]), ha_d = min_like_host(tb[7], tb[9]);
             if (ha_p < 1.005 * g_ap || ha_d < 1.005 * g_ad) {
                 TRY(madqp_copy(ctx, len, s->w2, s->st.d));  // the direction before it, whose step is already known
                 break;
             }
             g_ap = ha_p;
             g_ad = ha_d;
-            s->alpha_p = min_like_host(rb[14], rb[16]);
-            s->alpha_d = min_like_host(rb[18], rb[20]);
-            s->dnorm = rb[22];
+            s->alpha_p = min_like_host(tb[11], tb[13]);
+            s->alpha_d = min_like_host(tb[15], tb[17]);
+            s->dnorm = tb[19];
         }
     }
     // (c) update, objective, and the residuals the next termination test needs

@@ -109,16 +109,34 @@ extern "C" int32_t madqp_set_extra_correction(madqp_ctx* ctx, const madqp_state*
     CHECK_STATE();
     ProfScope ps(ctx, MADQP_PROF_VEC);
     LAUNCH(extra_correction_kernel, std::max(st->nlb, st->nub), *st, alpha_p, alpha_d,
-           beta_min * mu, beta_max * mu, nullptr);
+           beta_min * mu, beta_max * mu, nullptr, nullptr);
     return MADQP_OK;
 }
 // the same with mu in device memory: the kernel forms beta_min * mu, beta_max * mu
 int32_t madqp_set_extra_correction_dev(madqp_ctx* ctx, const madqp_state* st, double alpha_p, double alpha_d,
-                                       double beta_min, double beta_max, const double* mu_dev) {
+                                       double beta_min, double beta_max, const double* mu_dev, const double* a8) {
     CHECK_STATE();
     ARG_TRY(ctx, mu_dev != nullptr);
     ProfScope ps(ctx, MADQP_PROF_VEC);
-    LAUNCH(extra_correction_kernel, std::max(st->nlb, st->nub), *st, alpha_p, alpha_d, beta_min, beta_max, mu_dev);
+    LAUNCH(extra_correction_kernel, std::max(st->nlb, st->nub), *st, alpha_p, alpha_d, beta_min, beta_max, mu_dev, a8);
+    return MADQP_OK;
+}
+// min(alpha + delta, 1) for the primal and the dual step length of the block at res[in] (std::min's operand order twice,
+// as the host forms them), in the 8-slot pattern the step-length readers take
+__global__ void mpc_trial_alpha_kernel(double* __restrict__ res, int in, int out, double delta) {
+    if (threadIdx.x || blockIdx.x) return;
+    const double a0 = res[in], a1 = res[in + 2], a2 = res[in + 4], a3 = res[in + 6];
+    const double gp = ((a1 < a0) ? a1 : a0) + delta, gd = ((a3 < a2) ? a3 : a2) + delta;
+    const double tp = (1.0 < gp) ? 1.0 : gp, td = (1.0 < gd) ? 1.0 : gd;
+    res[out] = res[out + 2] = tp;
+    res[out + 4] = res[out + 6] = td;
+}
+int32_t madqp_q_mpc_trial_alpha(madqp_ctx* ctx, int in, int out, double delta) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, in >= 0 && in + 8 <= MADQP_FAULT_SLOT && out >= 0 && out + 8 <= MADQP_FAULT_SLOT);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    hipLaunchKernelGGL(mpc_trial_alpha_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_res, in, out, delta);
+    LAUNCH_CHECK(ctx);
     return MADQP_OK;
 }
 
