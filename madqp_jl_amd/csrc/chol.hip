@@ -1116,8 +1116,10 @@ static_assert(NB * XS_LD <= P2_S_DOUBLES + P2_WD_DOUBLES, "the operand image fit
 #else
 #define DS_STAMP(slot)
 #endif
+// zero_upper: the strictly upper sub-tiles are zeroed (the work area of the in-kernel inverse; the factor-only diagonal
+// kernel never touches them)
 __device__ __forceinline__ void mid_diag_syrk(const double* __restrict__ Ckk, const double* __restrict__ R, int64_t lda, int nb,
-                                              double* __restrict__ smem, int kstep) {
+                                              double* __restrict__ smem, int kstep, bool zero_upper) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, hi = lane >> 4;
     // this wave's tiles: row pair (p, 7 - p) has 9 lower tiles, waves 2p / 2p + 1 take the first 5 / last 4 of them
@@ -1182,7 +1184,7 @@ __device__ __forceinline__ void mid_diag_syrk(const double* __restrict__ Ckk, co
             double x = -acc[u][v];
             if (r >= nb || c >= nb) x = (r == c) ? 1.0 : 0.0;
             smem[c * LDS_LD + r] = (r >= c) ? x : 0.0;
-            if (tI[u] != tJ[u]) smem[(16 * tI[u] + hi + 4 * v) * LDS_LD + 16 * tJ[u] + lo] = 0.0;  // element (16 J + lo, 16 I + hi + 4 v)
+            if (zero_upper && tI[u] != tJ[u]) smem[(16 * tI[u] + hi + 4 * v) * LDS_LD + 16 * tJ[u] + lo] = 0.0;  // element (16 J + lo, 16 I + hi + 4 v)
         }
     }
     __syncthreads();
@@ -1281,7 +1283,7 @@ __global__ __launch_bounds__(MID_THREADS) void chol_mid_step_kernel(MidArgs a) {
     const bool own_syrk = diag && k > 0 && a.dsyrk;  // (uniform over the workgroup)
     if (own_syrk) {
         mid_diag_syrk(a.A + i0 + i0 * a.lda, a.A + i0 + (int64_t)(k - 1) * NB * a.lda, a.lda,
-                      (int)((a.n - i0 < NB) ? (a.n - i0) : NB), smem, k);
+                      (int)((a.n - i0 < NB) ? (a.n - i0) : NB), smem, k, /*zero_upper=*/!a.lite);
         MID_STAMP(1);
     } else if (k > 0) {
         GemmArgs g{};
@@ -1609,7 +1611,7 @@ static bool mid_plan_build(madqp_chol* s, int nblk, int cap) {
     std::vector<std::vector<MidVisit>> steps;
     std::vector<int32_t> units;
     bool ok = false;
-    for (int rounds = 1; rounds <= 64 && !ok; ++rounds) ok = mid_plan_steps(nblk, rounds * cap, steps, units);
+    for (int rounds = 1; rounds <= 64 && !ok; ++rounds) ok = mid_plan_steps(nblk, rounds * cap, steps, units, cap);
     if (!ok) return false;
     std::vector<uint32_t> w;
     s->mid_units = new (std::nothrow) int32_t[2 * nblk];

@@ -10,7 +10,7 @@ extern "C" int mid_plan_rows(int nblk, int cap, int32_t* out, int64_t max_rows, 
     std::vector<int32_t> units;
     int rounds = 0;
     for (int r = 1; r <= 64; ++r)
-        if (mid_plan_steps(nblk, r * cap, steps, units)) {
+        if (mid_plan_steps(nblk, r * cap, steps, units, cap)) {
             rounds = r;
             break;
         }
