@@ -64,6 +64,37 @@ int main() {
         (void)hipEventElapsedTime(&ms, e0, e1);
         printf("max  n=%6d partials(80) + final: %.2f us per pair\n", n, ms * 1e3 / reps);
     }
+    // the runtime's own small copies and fills in the same position (what hipMemcpyAsync D2D / hipMemsetAsync cost in a chain)
+    for (int n : {5000, 20000}) {
+        (void)hipEventRecord(e0, 0);
+        for (int r = 0; r < reps; ++r) {
+            hipLaunchKernelGGL(axpy_kernel, dim3(80), dim3(256), 0, 0, y, x, 1.0, n);
+            (void)hipMemcpyAsync(y, x, (size_t)n * 8, hipMemcpyDeviceToDevice, 0);
+        }
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("axpy + hipMemcpyAsync D2D n=%6d: %.2f us per pair\n", n, ms * 1e3 / reps);
+        (void)hipEventRecord(e0, 0);
+        for (int r = 0; r < reps; ++r) {
+            hipLaunchKernelGGL(axpy_kernel, dim3(80), dim3(256), 0, 0, y, x, 1.0, n);
+            (void)hipMemsetD32Async((hipDeviceptr_t)y, 0x7FF8A5A5, 2 * (size_t)n, 0);
+        }
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("axpy + hipMemsetD32Async     n=%6d: %.2f us per pair\n", n, ms * 1e3 / reps);
+        (void)hipEventRecord(e0, 0);
+        for (int r = 0; r < reps; ++r) {
+            hipLaunchKernelGGL(axpy_kernel, dim3(80), dim3(256), 0, 0, y, x, 1.0, n);
+            hipLaunchKernelGGL(axpy_kernel, dim3(80), dim3(256), 0, 0, y, x, 1.0, n);
+        }
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("axpy + axpy                  n=%6d: %.2f us per pair\n", n, ms * 1e3 / reps);
+    }
     // the same chain replayed from a graph: no host work per launch
     {
         hipStream_t st;
