@@ -1,8 +1,10 @@
 // Diagnostic build of the fused mid-size factorisation step with phase stamps (never part of the product):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DMADQP_MID_STAMPS -x hip tools/mid_probe.cpp \
 //         madqp_jl_amd/csrc/{gemm_f64,ctx,gen}.hip -ldl -o tools/mid_probe
-// Prints, per block step k, the phases of the workgroup holding the diagonal tile and of workgroup 1;
-// s_memrealtime, 100 MHz.
+// Prints, per block step k, the phases of the workgroup holding the diagonal tile and of workgroups 1 and 2;
+// s_memrealtime, 100 MHz.  With -DMADQP_POTF2_STAMPS as well: the phases of the diagonal kernel body inside the last step.
+// (A stamped build is scheduled differently from the product build: differences of a few percent between two variants
+// must be confirmed on the product build -- tools/mid_steps.py on a kernel trace of bench.py.)
 #include "../madqp_jl_amd/csrc/chol.hip"
 
 #include <cstdio>
