@@ -401,6 +401,70 @@ def batch_extra(M, be, seed):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def c2_extra(args, M, be):
+    """BASELINE configs[1] on this GPU, beside the headline (the number existed only in the builder's
+    own records): synthetic dense QP n_x = 5 000, m = 2 000 with SURVEY.md 8d's "dummy" Hessian family (H = G'G + 100 I,
+    MadNLPTests.DenseDummyQP of test/runtests.jl:9), the scripts' options, the same step definition as the headline --
+    (a) 60 timed iterations after 10 warm-up iterations with no kernel timers (an event pair around each of the ~80
+    short launches of a mid-size factorisation perturbs it); (b) a few more with the MFMA classes timed: the
+    factorisation's and the assembly's TFLOP/s against the fp64 MFMA peak; (c) one complete solve! by the reference's
+    definition (iter / total_time, src/solver.jl:353,392)."""
+    try:
+        nx, m = 5000, 2000
+        dq = M.DeviceQP.synthetic(be, args.seed, nx, m, "dummy")
+        opts = dict(max_iter=300, step_rule=M.AdaptiveStep(0.995), regularization=M.FixedRegularization(1e-8, -1e-8),
+                    mu_min=1e-12, max_ncorr=args.max_ncorr, scaling=True, driver=args.driver)
+        import torch
+
+        def timed(steps, warmup, classes):
+            solver = M.MPCSolver(dq, be, **opts)
+            solver.initialize()
+            loop = StepLoop(solver, torch.cuda.synchronize)
+            for _ in range(warmup):
+                loop.step()
+            be.prof_enable(classes)
+            be.prof_reset()
+            loop.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loop.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0 - loop.excluded
+            prof = be.prof_get()
+            be.prof_enable(())
+            nf = loop.factorizations()
+            solver.close()
+            return dt, prof, nf
+
+        dt, _, nf = timed(60, 10, ())
+        dt2, prof, nf2 = timed(20, 5, ("syrk", "potrf_gemm", "potrf_trsm", "potrf_diag"))
+        factor_ms = (prof["potrf_gemm"][0] + prof["potrf_trsm"][0] + prof["potrf_diag"][0]) / max(nf2, 1)
+        syrk_ms = prof["syrk"][0] / max(nf2, 1)
+        solver = M.MPCSolver(dq, be, **opts)
+        torch.cuda.synchronize()
+        r = solver.solve()
+        torch.cuda.synchronize()
+        solver.close()
+        tf = lambda flop, ms: (flop / (ms * 1e-3) * 1e-12) if ms > 0 else None
+        fr = lambda x: (x / PEAK_F64_MFMA_TFLOPS) if x else None
+        return {"metric": "IPM iterations/sec, value = steps / time of the timed iterations (initialize! excluded)",
+                "workload": f"synthetic dense QP nx={nx} m={m} (0<=x<=1, 0<=Ax<=1, dummy H = G'G + 100 I, Gaussian A), "
+                            f"max_ncorr={args.max_ncorr}",
+                "value": 60 / dt, "unit": "iterations/s", "ms_per_step": dt / 60 * 1e3, "steps": 60, "warmup": 10,
+                "factorizations": nf, "kernel_timers": "off in the timed region of `value`",
+                "with_mfma_timers": {"ms_per_step": dt2 / 20 * 1e3, "factor_potrf_ms": factor_ms, "assemble_syrk_ms": syrk_ms,
+                                     "factor_tflops": tf(nx ** 3 / 3.0, factor_ms),
+                                     "factor_frac_of_fp64_mfma_peak": fr(tf(nx ** 3 / 3.0, factor_ms)),
+                                     "assemble_tflops": tf(m * nx * nx, syrk_ms),
+                                     "assemble_frac_of_fp64_mfma_peak": fr(tf(m * nx * nx, syrk_ms))},
+                "whole_solve": {"status": int(r["status"]), "iter": int(r["iter"]), "total_time_s": r["total_time"],
+                                "iterations_per_s": r["iter"] / r["total_time"] if r["total_time"] > 0 else None,
+                                "n_factorizations": int(r["n_factorizations"]), "objective": float(r["objective"])}}
+    except Exception as e:  # the headline must not depend on it
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 class Product:
     """What is measured: the HIP library behind madqp_jl_amd (no fallback: the backend raises without a GPU)."""
 
@@ -641,6 +705,8 @@ def whole_solve(args, F, be):
     prof = be.prof_get()
     be.prof_enable(())
     nf = max(int(r["n_factorizations"]), 1)
+    timed = not args.no_kernel_timers  # (classes that were not timed are reported as null, never as 0.0)
+    trsv_timed = timed and "trsv" in classes
     factor_ms = prof["potrf_gemm"][0] + prof["potrf_trsm"][0] + prof["potrf_diag"][0]
     out = {"what": "ONE complete solve! (initialize! + all iterations), the reference's definitions: iter / "
                    "counters.total_time, counters.linear_solver_time / #factorizations (src/solver.jl:353,392; "
@@ -649,11 +715,14 @@ def whole_solve(args, F, be):
            "total_time_s": r["total_time"], "wall_s": wall,
            "iterations_per_s": r["iter"] / r["total_time"] if r["total_time"] > 0 else None,
            "n_factorizations": int(r["n_factorizations"]),
-           "linear_solver_time_s": factor_ms * 1e-3,
-           "linear_solver_ms_per_factorization": factor_ms / nf,
-           "build_kkt_ms_per_factorization": prof["syrk"][0] / nf,
-           "solve_sweeps_ms_per_factorization": (prof["trsv"][0] / nf) if prof["trsv"][1] else None,
-           "kkt_factor_solve_ms_per_factorization": (factor_ms + prof["syrk"][0] + prof["trsv"][0]) / nf,
+           "linear_solver_time_s": factor_ms * 1e-3 if timed else None,
+           "linear_solver_ms_per_factorization": factor_ms / nf if timed else None,
+           "build_kkt_ms_per_factorization": prof["syrk"][0] / nf if timed else None,
+           "solve_sweeps_ms_per_factorization": (prof["trsv"][0] / nf) if trsv_timed else None,
+           # assembly + factorisation + the sweeps of every solve that follows it; null when the sweeps were not timed
+           # (below nx = 20 000 an event pair around a 100 us sweep perturbs the iteration)
+           "kkt_factor_solve_ms_per_factorization": ((factor_ms + prof["syrk"][0] + prof["trsv"][0]) / nf) if trsv_timed else None,
+           "kkt_build_factor_ms_per_factorization": ((factor_ms + prof["syrk"][0]) / nf) if timed else None,
            "objective": float(r["objective"]), "primal_feas": float(r["primal_feas"]), "dual_feas": float(r["dual_feas"])}
     solver.close()
     del solver, dq
@@ -686,9 +755,14 @@ def bench_line(args, res, world, F=None):
                     "(csrc/dist.hip)"}[mode]
     par = "independent" if mode == "local" else "grid %dx%d nb=%d" % (*res["layout"]["grid"], res["layout"]["tile"])
     out = {
-        "metric": ("IPM iterations/sec (Mehrotra predictor-corrector, condensed KKT + Cholesky), dense QP fp64"
+        # `value` = timed iterations / their time (a step is one iteration; initialize! is outside the timed region).  The
+        # reference's own rate, iter / counters.total_time of ONE complete solve! with initialize! inside
+        # (src/solver.jl:353,392), is `value_reference_definition` = whole_solve.iterations_per_s below.
+        "metric": ("IPM iterations/sec (Mehrotra predictor-corrector, condensed KKT + Cholesky), dense QP fp64; value = "
+                   "steps / time of the timed iterations, initialize! excluded (value_reference_definition: iter / total_time)"
                    if args.kkt_system == "condensed" else
-                   "IPM iterations/sec (Mehrotra predictor-corrector, augmented K2 KKT, L diag(I,-I) L'), dense QP fp64"),
+                   "IPM iterations/sec (Mehrotra predictor-corrector, augmented K2 KKT, L diag(I,-I) L'), dense QP fp64; value "
+                   "= steps / time of the timed iterations, initialize! excluded"),
         "value": (steps / tmax) if shared else job_value(world, steps, tmax),
         "unit": "iterations/s",
         "n_gpus": world,
@@ -910,8 +984,9 @@ def main():
                 out["whole_solve"] = whole_solve(args, F, be)
             except Exception as e:  # the headline must not depend on it
                 out["whole_solve"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            out["value_reference_definition"] = out["whole_solve"].get("iterations_per_s")
         if rank == 0 and world == 1 and mode == "local" and not args.no_batch_extra and F.cuda:
-            out["extras"] = {"batch_1024x512x256": batch_extra(M, be, args.seed)}
+            out["extras"] = {"c2_nx5000_m2000": c2_extra(args, M, be), "batch_1024x512x256": batch_extra(M, be, args.seed)}
         if rank == 0 and world == 1 and not args.no_cpu_baseline and F.cuda:
             out["cpu_baseline"] = cpu_baseline(args, nx, m, M, be)
         if rank == 0:

@@ -183,7 +183,9 @@ int32_t madqp_get_affine_complementarity_measure(madqp_ctx* ctx, const madqp_sta
 /* get_alpha_max_primal + get_alpha_max_dual (src/kernels.jl:242-288) in one launch.
  * alpha_host[4] = (alpha_xl, alpha_xu, alpha_zl, alpha_zu); iblock_host[4] = 0-based blocking
  * index into the lb/ub lists, -1 when nothing blocks (the reference's init (1.0, 0)).
- * Ties resolve to the smallest index (first minimum under the reference's strict '<'). */
+ * Exact ties resolve to the LAST index among the minima: src/kernels.jl:248 compares `a[1] < b[1] ? a : b` and mapreduce
+ * folds from the left, so a later element with the same ratio replaces the earlier one (tests/test_gpu_kernels.py folds
+ * the reference's reducer literally). */
 int32_t madqp_get_alpha_max(madqp_ctx* ctx, const madqp_state* st, double tau,
                             double* alpha_host, int64_t* iblock_host);
 /* axpy! x4 of src/solver.jl:332-335 */
@@ -360,9 +362,11 @@ int32_t madqp_chol_panel_pack(madqp_chol* s, int64_t j0, int64_t w, double* buf)
  *   layout   tile (I, J) of the lower triangle (nb x nb, nb a multiple of 128) lives on rank (I mod P, J mod Q) at
  *            position (I div P, J div Q) of that rank's column-major local matrix (madqp_dist_matrix): the caller (or
  *            madqp_dkkt_*) fills the local tiles with K, factor overwrites them with L;
- *   factor   right-looking over tile columns with look-ahead 1: diagonal tile -> broadcast down its process column ->
- *            panel solves -> the panel is broadcast along process rows and, transposed, down process columns -> one
- *            MFMA GEMM per rank and step; info as LAPACK dpotrf, identical on all ranks;
+ *   factor   over tile columns with look-ahead 1 in the panel phase: diagonal tile -> broadcast down its process column ->
+ *            panel solves -> the panel is broadcast along process rows and, transposed, down process columns; the
+ *            UPDATES are left-looking and lazy: a rank keeps the operands of all steps and brings a tile column up to
+ *            date in one wide-K MFMA GEMM when it is needed (csrc/dist_core.inc); info as LAPACK dpotrf, identical on
+ *            all ranks;
  *   solve    rhs: n doubles, replicated on every rank, overwritten with the solution.  Forward and backward sweeps
  *            over GROUPS of G tiles (G nb = 4096 rows by default): during the factorisation the G x G tile triangle on
  *            the diagonal of each group is collected on one rank (group g -> rank g mod world; point-to-point, <= G

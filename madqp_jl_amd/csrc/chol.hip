@@ -280,9 +280,11 @@ __device__ __forceinline__ void potf2_inv_body(double* __restrict__ A, int64_t l
         for (int i = 0; i < NB / CG; ++i) S[(c0 + CG * i) * LDS_LD + r] = v[i];
     }
     if (MODE == 2) {  // the sub-block inverses the factor-only kernel left on the diagonal of the column-major image
+        // (rows at or beyond the order of a short block were never written by that kernel: identity padding, as MODE 0 has)
         for (int e = tid; e < NSB * SB * SB; e += NT) {
             const int J = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
-            Wd[(J * SB + rr) * WD_LD + cc] = (cc <= rr) ? Wcm[(SB * J + cc) * NB + SB * J + rr] : 0.0;
+            const double wv = Wcm[(SB * J + cc) * NB + SB * J + rr];
+            Wd[(J * SB + rr) * WD_LD + cc] = (SB * J + rr < nb) ? ((cc <= rr) ? wv : 0.0) : ((rr == cc) ? 1.0 : 0.0);
         }
     }
     __syncthreads();
@@ -481,6 +483,61 @@ __global__ __launch_bounds__(P2_KTHREADS) void potf2_invert_kernel(double* __res
     potf2_inv_body<P2_KTHREADS, 2>(A + jb + jb * lda, lda, nb, Wcm, Wcm + NB * NB, nullptr, 0, S, Wd);
 }
 
+// The off-diagonal 16 x 16 sub-blocks of both sweep images of the diagonal blocks j0/128 .. of a factored matrix, one
+// workgroup per block, ONE launch per factorisation (see "the diagonal step of a sweep" below): image 1 (column-major)
+// gets Lt_IJ = L_IJ W_JJ at (16 I.., 16 J..), image 2 gets Lh_IJ = W_II L_IJ transposed, i.e. at [(16 I + k) NB + 16 J + c]
+// -- the places the 128 x 128 inverse and its transpose used to fill; the diagonals (W_JJ, left by the factor-only
+// diagonal kernels) stay.  normalise = 0: the sub-blocks of L themselves (plain block substitution, MADQP_SWEEP_DIAG=sub16).
+__global__ __launch_bounds__(256) void sweep_image_kernel(const double* __restrict__ A, int64_t lda, int64_t n, int64_t j0,
+                                                          double* __restrict__ winv, int normalise) {
+    __shared__ double S[P2_S_DOUBLES];   // S[c*LDS_LD + r] = L(r, c), zero beyond the order of a short block
+    __shared__ double Wd[P2_WD_DOUBLES]; // W_JJ[r][c] at (J*SB + r)*WD_LD + c
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 15, hi = lane >> 4;
+    const int64_t jb = j0 + (int64_t)blockIdx.x * NB;
+    const int nb = (int)((n - jb < NB) ? (n - jb) : NB);
+    double* Wcm = winv + (jb / NB) * WBLK;
+    double* Wrm = Wcm + NB * NB;
+    const double* Ab = A + jb + jb * lda;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e & (NB - 1), c = e >> 7;
+        const int rr = r < nb ? r : nb - 1, cc = c < nb ? c : nb - 1;  // (unconditional loads from addresses that exist)
+        const double v = Ab[rr + (int64_t)cc * lda];
+        S[c * LDS_LD + r] = (r < nb && c <= r) ? v : 0.0;
+    }
+    for (int e = tid; e < NSB * SB * SB; e += 256) {
+        const int J = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
+        const double v = Wcm[(SB * J + cc) * NB + SB * J + rr];
+        Wd[(J * SB + rr) * WD_LD + cc] = (cc <= rr) ? v : 0.0;
+    }
+    __syncthreads();
+    for (int p = wave; p < NSB * (NSB - 1) / 2; p += 4) {
+        int I = 1, q = p;  // pair p -> (I, J), I > J
+        while (q >= I) {
+            q -= I;
+            ++I;
+        }
+        const int J = q;
+        double4_t P = {0.0, 0.0, 0.0, 0.0}, Q = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int k = 4 * s4 + hi;
+            // P = L_IJ W_JJ: A[m = lo][k] = L_IJ[lo][k], B[k][n = lo] = W_JJ[k][lo]
+            const double pa = S[(SB * J + k) * LDS_LD + SB * I + lo];
+            const double pb = normalise ? Wd[(J * SB + k) * WD_LD + lo] : (k == lo ? 1.0 : 0.0);
+            P = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, P, 0, 0, 0);
+            // Q = W_II L_IJ: A[m = lo][k] = W_II[lo][k], B[k][n = lo] = L_IJ[k][lo]
+            const double qa = normalise ? Wd[(I * SB + lo) * WD_LD + k] : (k == lo ? 1.0 : 0.0);
+            const double qb = S[(SB * J + lo) * LDS_LD + SB * I + k];
+            Q = __builtin_amdgcn_mfma_f64_16x16x4f64(qa, qb, Q, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {  // D[m = hi + 4v][n = lo]
+            Wcm[(SB * J + lo) * NB + SB * I + hi + 4 * v] = P[v];
+            Wrm[(SB * I + hi + 4 * v) * NB + SB * J + lo] = Q[v];
+        }
+    }
+}
+
 // ---- triangular sweeps, one launch each ---------------------------------------------------------
 // A sweep over the 128-row blocks is a chain: block r needs the solutions of all blocks before it.
 // Instead of one launch per block (391 launches per sweep at n = 50 000, each with its own ramp and
@@ -603,39 +660,159 @@ __device__ __forceinline__ double sweep_block_product(const double2_t (&w0)[4], 
     }
     return sum;
 }
-// this thread's corner of the DIAGONAL tile (rows 2 lane, 2 lane + 1; columns c0 .. c0 + 3), lower triangle only, zero
-// beyond the order w of the (last, short) block: the upper triangle of a diagonal tile holds whatever the assembly left
-__device__ __forceinline__ void sweep_load_diag(const double* __restrict__ Lrr, int64_t ld, int lane, int c0, int w,
-                                                bool vec, double2_t (&dst)[4]) {
-    // every load is unconditional, from an address that always exists (indices clamped into the block), and the triangle /
-    // order masks are selects afterwards: a load under a condition is followed by its own wait -- 32 dependent round
-    // trips in front of the first blocks of a sweep
-    const int i0 = 2 * lane;
-    if (vec && w == NB) {  // (wave-uniform)
+// ---- the diagonal step of a sweep by UNIT BLOCK SUBSTITUTION over the 16 x 16 sub-blocks (round 5) -----------------------
+// A product with the stored 128 x 128 inverse leaves a residual of cond(L_rr) eps where substitution leaves eps, and the
+// interior-point iterates see the residual: on ill-conditioned problems the per-iteration traces sat up to 80 x the CPU
+// noise floor from LAPACK's (profiles/r04_parity_ratios_default.json; tools/numerics/blockchol_emul.py: it is the product
+// with ANY stored 128-inverse, while block substitution over 16 x 16 sub-blocks is statistically as good as dtrsv).  The
+// sweeps therefore substitute: with W_JJ = (L_rr)_JJ^-1 (16 x 16, left on the images' diagonals by the factor-only
+// diagonal kernel) and the off-diagonal sub-blocks normalised ONCE per factorisation (sweep_image_kernel),
+//     forward   Lt_IJ = L_IJ W_JJ :   u_I = v_I - sum_{J<I} Lt_IJ u_J,    z_I = W_II u_I
+//     backward  Lh_IJ = W_II L_IJ :   w_J = v_J - sum_{I>J} Lh_IJ' w_I,   x_J = W_JJ' w_J
+// (the same error bound as z_I = W_II (v_I - sum L_IJ z_J): the 16 x 16 inverses enter once per term either way), so
+// that ONE broadcast of the 16 values u_J serves both the rows of sub-block J (-> z_J) and every row below (-> update):
+// eight steps of 32 read-lanes + 32 fused multiply-adds on ONE wave, no barrier, no LDS round trip on the chain.
+// DIAG = 2 keeps plain block substitution (images hold L_IJ itself; a second broadcast per step) for A/B runs,
+// DIAG = 0 the product with the 128 x 128 inverse (MADQP_SWEEP_DIAG=inv, and whenever the images hold full inverses).
+// The image of a block sits in LDS packed by columns: forward column c (sub-block J) holds rows 16 J .. 127, backward
+// column q (sub-block I) rows 0 .. 16 I + 15; a lane reads consecutive rows of one column: conflict free.
+constexpr int XIMG_DOUBLES = 16 * (8 * NB - 16 * 28);                                               // 9 216
+__host__ __device__ constexpr int ximg_f_col(int J) { return 16 * (NB * J - 8 * J * (J - 1)); }      // first column of sub-block J
+__host__ __device__ constexpr int ximg_b_col(int I) { return NB * I * (I + 1); }
+static_assert(ximg_f_col(8) == XIMG_DOUBLES && ximg_b_col(8) == XIMG_DOUBLES, "packed image size");
+
+// the column-major 128 x 128 image G (global) -> packed LDS image; all 1024 threads, 16 loads each in flight at once
+// (load and store are separate calls so that the first tile loads of the sweep can be issued between them)
+__device__ __forceinline__ void ximg_load(const double* __restrict__ G, int tid, double (&v)[16]) {
+    const int r = tid & (NB - 1), cg = tid >> 7;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = c0 + q;
-            const double2_t v = *reinterpret_cast<const double2_t*>(Lrr + i0 + (int64_t)c * ld);
-            dst[q].x = (c <= i0) ? v.x : 0.0;
-            dst[q].y = (c <= i0 + 1) ? v.y : 0.0;
-        }
-    } else {
-        const int ia = i0 < w ? i0 : w - 1, ib = i0 + 1 < w ? i0 + 1 : w - 1;
+    for (int i = 0; i < 16; ++i) v[i] = G[(cg + 8 * i) * NB + r];
+}
+template <bool BWD>
+__device__ __forceinline__ void ximg_store(const double (&v)[16], double* __restrict__ X, int tid) {
+    const int r = tid & (NB - 1), cg = tid >> 7;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = c0 + q, cc = c < w ? c : w - 1;
-            const double vx = Lrr[ia + (int64_t)cc * ld], vy = Lrr[ib + (int64_t)cc * ld];
-            dst[q].x = (c < w && i0 < w && c <= i0) ? vx : 0.0;
-            dst[q].y = (c < w && i0 + 1 < w && c <= i0 + 1) ? vy : 0.0;
+    for (int i = 0; i < 16; ++i) {
+        const int B = i >> 1, ck = cg + 8 * (i & 1);  // sub-block and column inside it
+        if (!BWD) {
+            if (r >= 16 * B) X[ximg_f_col(B) + ck * (NB - 16 * B) + r - 16 * B] = v[i];
+        } else {
+            if (r < 16 * (B + 1)) X[ximg_b_col(B) + ck * 16 * (B + 1) + r] = v[i];
         }
     }
+}
+
+// wave 0: the 128 values of the diagonal step; lane l holds rows l (u0) and 64 + l (u1) on entry (v) and on return (z)
+template <int DIAG>
+__device__ __attribute__((noinline)) double2_t sweep_diag_fwd(const double* __restrict__ X, int lane, double u0, double u1) {
+    const int I0 = lane >> 4;  // sub-block of row `lane`; row 64 + lane sits in sub-block 4 + I0
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+        const int len = NB - 16 * J, base = ximg_f_col(J) - 16 * J;
+        const double src = (J < 4) ? u0 : u1;
+        double b[16], x0[16], x1[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (J < 4) x0[k] = X[base + k * len + lane];  // (lanes above sub-block J read a neighbour's entries: discarded)
+            x1[k] = X[base + k * len + 64 + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) b[k] = readlane_f64(src, 16 * (J & 3) + k);
+        double t0a = 0.0, t0b = 0.0, t1a = 0.0, t1b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            if (J < 4) {
+                t0a = __builtin_fma(x0[k], b[k], t0a);
+                t0b = __builtin_fma(x0[k + 1], b[k + 1], t0b);
+            }
+            t1a = __builtin_fma(x1[k], b[k], t1a);
+            t1b = __builtin_fma(x1[k + 1], b[k + 1], t1b);
+        }
+        double t0 = t0a + t0b, t1 = t1a + t1b;
+        if (DIAG == 2) {  // plain block substitution: the rows below take z_J, not u_J
+            const double zsrc = (J < 4) ? t0 : t1;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) b[k] = readlane_f64(zsrc, 16 * (J & 3) + k);
+            double s0a = 0.0, s0b = 0.0, s1a = 0.0, s1b = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                if (J < 4) {
+                    s0a = __builtin_fma(x0[k], b[k], s0a);
+                    s0b = __builtin_fma(x0[k + 1], b[k + 1], s0b);
+                }
+                s1a = __builtin_fma(x1[k], b[k], s1a);
+                s1b = __builtin_fma(x1[k + 1], b[k + 1], s1b);
+            }
+            if (J < 4) t0 = (I0 == J) ? t0 : s0a + s0b;
+            t1 = (4 + I0 == J) ? t1 : s1a + s1b;
+        }
+        if (J < 4) {
+            u0 = (I0 == J) ? t0 : (I0 > J) ? u0 - t0 : u0;
+            u1 = u1 - t1;
+        } else {
+            u1 = (4 + I0 == J) ? t1 : (4 + I0 > J) ? u1 - t1 : u1;
+        }
+    }
+    return double2_t{u0, u1};
+}
+template <int DIAG>
+__device__ __attribute__((noinline)) double2_t sweep_diag_bwd(const double* __restrict__ X, int lane, double u0, double u1) {
+    const int J0 = lane >> 4;  // sub-block of entry `lane`; entry 64 + lane: 4 + J0
+#pragma unroll
+    for (int I = 7; I >= 0; --I) {
+        const int len = 16 * (I + 1), base = ximg_b_col(I);
+        const double src = (I < 4) ? u0 : u1;
+        double b[16], x0[16], x1[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            x0[k] = X[base + k * len + lane];  // (entries beyond sub-block I read a neighbour's column: discarded)
+            if (I >= 4) x1[k] = X[base + k * len + 64 + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) b[k] = readlane_f64(src, 16 * (I & 3) + k);
+        double t0a = 0.0, t0b = 0.0, t1a = 0.0, t1b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            t0a = __builtin_fma(x0[k], b[k], t0a);
+            t0b = __builtin_fma(x0[k + 1], b[k + 1], t0b);
+            if (I >= 4) {
+                t1a = __builtin_fma(x1[k], b[k], t1a);
+                t1b = __builtin_fma(x1[k + 1], b[k + 1], t1b);
+            }
+        }
+        double t0 = t0a + t0b, t1 = t1a + t1b;
+        if (DIAG == 2) {
+            const double zsrc = (I < 4) ? t0 : t1;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) b[k] = readlane_f64(zsrc, 16 * (I & 3) + k);
+            double s0a = 0.0, s0b = 0.0, s1a = 0.0, s1b = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                s0a = __builtin_fma(x0[k], b[k], s0a);
+                s0b = __builtin_fma(x0[k + 1], b[k + 1], s0b);
+                if (I >= 4) {
+                    s1a = __builtin_fma(x1[k], b[k], s1a);
+                    s1b = __builtin_fma(x1[k + 1], b[k + 1], s1b);
+                }
+            }
+            t0 = (J0 == I) ? t0 : s0a + s0b;
+            if (I >= 4) t1 = (4 + J0 == I) ? t1 : s1a + s1b;
+        }
+        if (I >= 4) {
+            u1 = (4 + J0 == I) ? t1 : (4 + J0 < I) ? u1 - t1 : u1;
+            u0 = u0 - t0;
+        } else {
+            u0 = (J0 == I) ? t0 : (J0 < I) ? u0 - t0 : u0;
+        }
+    }
+    return double2_t{u0, u1};
 }
 
 __global__ __launch_bounds__(256) void negate_kernel(double* __restrict__ v, int64_t len) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) v[i] = -v[i];
 }
 
-template <bool REFINE>
+template <int DIAG>
 __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __restrict__ L, int64_t lda,
                                                               const double* __restrict__ winv,
                                                               const double* __restrict__ b,
@@ -645,6 +822,7 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     __shared__ double xs[2][NB];
     __shared__ double red[16][NB];
     __shared__ double vs[NB];
+    __shared__ double ximg[DIAG ? XIMG_DOUBLES : 1];
     __shared__ int s_r;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_r = atomicAdd(&ctl[1], 1);
@@ -661,30 +839,24 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     const int64_t row0 = (int64_t)r * NB;
     const int w = (int)((n - row0 < NB) ? (n - row0) : NB);
     const bool ok0 = row0 + 2 * lane < n, ok1 = row0 + 2 * lane + 1 < n;
-    // inverse diagonal block (column-major image, zero padded, 16-byte aligned): registers
-    // REFINE (MADQP_SWEEP_REFINE=1, off by default): also this thread's corner of the diagonal tile itself (lower
-    // triangle), for a refined diagonal step
-    //     z0 = W v,   z = z0 + W (v - L_rr z0).
-    // A product with the stored inverse alone leaves a residual of cond(L_rr) eps where substitution leaves eps; on the
-    // ill-conditioned random problems of the soak the per-iteration traces then sit up to 80 x the CPU noise floor from
-    // LAPACK's, with the refined step within 1 x (profiles/r04_parity_ratios_*.json) -- solutions and objectives meet the
-    // stated bar either way.  Two more 128 x 128 products with their barriers on the hand-off chain and 16 more live
-    // registers per thread (the kernel spills): +1.8 ms per sweep at n = 50 000, +0.9 ms per iteration at n = 5 000.
-    double2_t W0[4], W1[4], D0[4], D1[4];
+    // DIAG = 0: the inverse diagonal block (column-major image, zero padded, 16-byte aligned) in registers;
+    // else: this block's forward image (16 x 16 inverses on the diagonal, normalised sub-blocks below) packed into LDS
+    double2_t W0[4], W1[4];
+    double xv[16];
     if (owner) {
-        const double* Wcm = winv + (int64_t)r * WBLK + 2 * lane;
-        sweep_load_half(Wcm + (int64_t)(wave * 4) * NB, NB, true, true, true, W0);
-        sweep_load_half(Wcm + (int64_t)(64 + wave * 4) * NB, NB, true, true, true, W1);
-        if (REFINE) {
-            const double* Lrr = L + row0 + row0 * lda;
-            sweep_load_diag(Lrr, lda, lane, wave * 4, w, vec != 0, D0);
-            sweep_load_diag(Lrr, lda, lane, 64 + wave * 4, w, vec != 0, D1);
+        const double* Wcm = winv + (int64_t)r * WBLK;
+        if (DIAG == 0) {
+            sweep_load_half(Wcm + 2 * lane + (int64_t)(wave * 4) * NB, NB, true, true, true, W0);
+            sweep_load_half(Wcm + 2 * lane + (int64_t)(64 + wave * 4) * NB, NB, true, true, true, W1);
+        } else {
+            ximg_load(Wcm, tid, xv);
         }
     }
     double a0 = 0.0, a1 = 0.0;
     const double* Lr = L + row0 + 2 * lane + (int64_t)(wave * 4) * lda;  // this thread's corner of tile (r, 0)
     double2_t A[4], B[4];
     if (j1 > j0) sweep_load_half(Lr + (int64_t)j0 * NB * lda, lda, ok0, ok1, vec, A);
+    if (DIAG != 0 && owner) ximg_store<false>(xv, ximg, tid);  // (visible to wave 0 after any later barrier)
     for (int j = j0; j < j1; ++j) {
         const double* Tj = Lr + (int64_t)j * NB * lda;
         sweep_load_half(Tj + 64 * lda, lda, ok0, ok1, vec, B);
@@ -723,21 +895,18 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     }
     if (!owner) return;
     __syncthreads();
-    const double z0 = sweep_block_product(W0, W1, vs, red, tid, lane, wave);  // z0 = W v
-    if (!REFINE) {
+    if (DIAG == 0) {
+        const double z0 = sweep_block_product(W0, W1, vs, red, tid, lane, wave);  // z = W v
         if (tid < w) st_sc1_f64(y + row0 + tid, z0);
         return;
     }
-    if (tid < NB) xs[0][tid] = z0;
-    __syncthreads();
-    const double lz = sweep_block_product(D0, D1, xs[0], red, tid, lane, wave);  // L_rr z0
-    if (tid < NB) xs[1][tid] = (tid < w) ? vs[tid] - lz : 0.0;                    // residual of the block
-    __syncthreads();
-    const double dz = sweep_block_product(W0, W1, xs[1], red, tid, lane, wave);  // W (v - L_rr z0)
-    if (tid < w) st_sc1_f64(y + row0 + tid, z0 + dz);
+    if (wave != 0) return;  // (the image was complete before the first barrier of this workgroup)
+    const double2_t z = sweep_diag_fwd<DIAG>(ximg, lane, vs[lane], vs[64 + lane]);
+    if (lane < w) st_sc1_f64(y + row0 + lane, z.x);
+    if (64 + lane < w) st_sc1_f64(y + row0 + 64 + lane, z.y);
 }
 
-template <bool REFINE>
+template <int DIAG>
 __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __restrict__ L, int64_t lda,
                                                               const double* __restrict__ winv,
                                                               const double* __restrict__ y,
@@ -745,9 +914,10 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
                                                               int32_t* __restrict__ ctl, double* __restrict__ fault,
                                                               int vec, SweepPlan plan) {
     __shared__ double xs[2][NB];
-    __shared__ double red[16][NB];
+    __shared__ double red[DIAG ? 1 : 16][NB];
     __shared__ double vs[NB];
     __shared__ double colred[NB][65];  // column-sum staging, padded against bank conflicts
+    __shared__ double ximg[DIAG ? XIMG_DOUBLES : 1];
     __shared__ int s_r;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = (int)((n + NB - 1) / NB);
@@ -766,18 +936,17 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
     const int r = nblk - 1 - rr;
     const int64_t col0 = (int64_t)r * NB;
     const int w = (int)((n - col0 < NB) ? (n - col0) : NB);
-    // W' v through the row-major image: Wrm[c + r*NB] = W(r, c) -> output index c is the fast one
-    // + this thread's corner of the diagonal tile for the refined diagonal step (see the forward kernel):
-    //     x0 = W' v,   x = x0 + W' (v - L_rr' x0)
-    double2_t W0[4], W1[4], D0[4], D1[4];
+    // DIAG = 0: W' v through the row-major image (Wrm[c + r*NB] = W(r, c): output index c is the fast one), in registers;
+    // else: this block's backward image packed into LDS
+    double2_t W0[4], W1[4];
+    double xv[16];
     if (owner) {
-        const double* Wrm = winv + (int64_t)r * WBLK + NB * NB + 2 * lane;
-        sweep_load_half(Wrm + (int64_t)(wave * 4) * NB, NB, true, true, true, W0);
-        sweep_load_half(Wrm + (int64_t)(64 + wave * 4) * NB, NB, true, true, true, W1);
-        if (REFINE) {
-            const double* Lrr = L + col0 + col0 * lda;
-            sweep_load_diag(Lrr, lda, lane, wave * 4, w, vec != 0, D0);
-            sweep_load_diag(Lrr, lda, lane, 64 + wave * 4, w, vec != 0, D1);
+        const double* Wrm = winv + (int64_t)r * WBLK + NB * NB;
+        if (DIAG == 0) {
+            sweep_load_half(Wrm + 2 * lane + (int64_t)(wave * 4) * NB, NB, true, true, true, W0);
+            sweep_load_half(Wrm + 2 * lane + (int64_t)(64 + wave * 4) * NB, NB, true, true, true, W1);
+        } else {
+            ximg_load(Wrm, tid, xv);
         }
     }
     // this thread's columns: col0 + h*64 + wave*4 + q; rows 2*lane, 2*lane+1 of the row block j
@@ -800,6 +969,7 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
         rows_ok(jhi, o0, o1);
         sweep_load_half(Lc + (int64_t)jhi * NB, lda, o0, o1, vec, A);
     }
+    if (DIAG != 0 && owner) ximg_store<true>(xv, ximg, tid);
     for (int j = jhi; j > jlo; --j) {
         bool o0, o1;
         rows_ok(j, o0, o1);
@@ -849,33 +1019,15 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
         vs[tid] = (tid < w) ? (y[col0 + tid] - (far + vs[tid])) : 0.0;
     }
     __syncthreads();
-    const double x0 = sweep_block_product(W0, W1, vs, red, tid, lane, wave);  // x0 = W' v
-    if (!REFINE) {
+    if (DIAG == 0) {
+        const double x0 = sweep_block_product(W0, W1, vs, red, tid, lane, wave);  // x = W' v
         if (tid < w) st_sc1_f64(x + col0 + tid, x0);
         return;
     }
-    if (tid < NB) xs[0][tid] = x0;
-    __syncthreads();
-    {   // L_rr' x0: column sums of the diagonal tile weighted with the rows of x0, reduced like the streamed tiles
-        const double r0 = xs[0][2 * lane], r1 = xs[0][2 * lane + 1];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            colred[wave * 4 + q][lane] = __builtin_fma(D0[q].y, r1, D0[q].x * r0);
-            colred[64 + wave * 4 + q][lane] = __builtin_fma(D1[q].y, r1, D1[q].x * r0);
-        }
-        __syncthreads();
-        const int cl = tid >> 3, part = tid & 7;
-        double t = 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t += colred[cl][part * 8 + u];
-        t += __shfl_down(t, 4, 8);
-        t += __shfl_down(t, 2, 8);
-        t += __shfl_down(t, 1, 8);
-        if (part == 0) xs[1][cl] = (cl < w) ? vs[cl] - t : 0.0;  // residual of the block
-    }
-    __syncthreads();
-    const double dx = sweep_block_product(W0, W1, xs[1], red, tid, lane, wave);  // W' (v - L_rr' x0)
-    if (tid < w) st_sc1_f64(x + col0 + tid, x0 + dx);
+    if (wave != 0) return;
+    const double2_t z = sweep_diag_bwd<DIAG>(ximg, lane, vs[lane], vs[64 + lane]);
+    if (lane < w) st_sc1_f64(x + col0 + lane, z.x);
+    if (64 + lane < w) st_sc1_f64(x + col0 + 64 + lane, z.y);
 }
 
 // ---- panel times inverse for ONE 128-column block: L[rows, :] = C[rows, :] W'  (W = inverse of the block's factor) ----
@@ -1503,18 +1655,49 @@ static bool chol_lite() {
     static const bool on = !(getenv("MADQP_CHOL_LITE") && atoi(getenv("MADQP_CHOL_LITE")) == 0);
     return on && !panel_inv_mode();
 }
+// The diagonal step of the sweeps: 1 = unit block substitution with normalised images (default), 2 = plain block
+// substitution over the 16 x 16 sub-blocks (MADQP_SWEEP_DIAG=sub16), 0 = the product with the stored 128 x 128 inverse of
+// rounds 1-4 (MADQP_SWEEP_DIAG=inv; also whenever the diagonal kernels factor AND invert: MADQP_CHOL_LITE=0 /
+// MADQP_CHOL_PANEL=inv, whose images are full inverses).
+static int sweep_diag_mode() {
+    static const int mode = [] {
+        const char* e = getenv("MADQP_SWEEP_DIAG");
+        if (e && strcmp(e, "inv") == 0) return 0;
+        if (e && strcmp(e, "sub16") == 0) return 2;
+        return 1;
+    }();
+    return chol_lite() ? mode : 0;
+}
+// what the factor-only diagonal kernels leave out of the serial spine, for all blocks j0/128 .. in ONE launch: the
+// off-diagonal parts of the sweep images
 static int32_t invert_blocks(madqp_chol* s, double* A, int64_t lda, int64_t j0, int64_t w) {
     if (w <= 0 || !chol_lite()) return MADQP_OK;
     madqp_ctx* ctx = s->ctx;
     ProfScope ps(ctx, MADQP_PROF_POTRF_DIAG);
-    hipLaunchKernelGGL(potf2_invert_kernel, dim3((unsigned)((w + NB - 1) / NB)), dim3(P2_KTHREADS), 0, ctx->stream, A, lda, s->n, j0,
-                       s->winv);
+    const unsigned nblk = (unsigned)((w + NB - 1) / NB);
+    if (sweep_diag_mode() == 0)
+        hipLaunchKernelGGL(potf2_invert_kernel, dim3(nblk), dim3(P2_KTHREADS), 0, ctx->stream, A, lda, s->n, j0, s->winv);
+    else
+        hipLaunchKernelGGL(sweep_image_kernel, dim3(nblk), dim3(256), 0, ctx->stream, A, lda, s->n, j0, s->winv,
+                           sweep_diag_mode() == 1 ? 1 : 0);
     LAUNCH_CHECK(ctx);
     return MADQP_OK;
 }
-static bool sweep_refine() {  // the refined diagonal step of both sweeps (trsv_*_sweep_kernel<true>); off by default
-    static const bool on = getenv("MADQP_SWEEP_REFINE") && atoi(getenv("MADQP_SWEEP_REFINE")) != 0;
-    return on;
+template <int DIAG>
+static void launch_sweep(bool bwd, unsigned grid, hipStream_t st, const double* L, int64_t ld, const double* winv, const double* in,
+                         double* out, int64_t n, int32_t* ctl, double* fault, int vec, const SweepPlan& plan) {
+    if (bwd)
+        hipLaunchKernelGGL(trsv_bwd_sweep_kernel<DIAG>, dim3(grid), dim3(1024), 0, st, L, ld, winv, in, out, n, ctl, fault, vec, plan);
+    else
+        hipLaunchKernelGGL(trsv_fwd_sweep_kernel<DIAG>, dim3(grid), dim3(1024), 0, st, L, ld, winv, in, out, n, ctl, fault, vec, plan);
+}
+static void launch_sweep(bool bwd, unsigned grid, hipStream_t st, const double* L, int64_t ld, const double* winv, const double* in,
+                         double* out, int64_t n, int32_t* ctl, double* fault, int vec, const SweepPlan& plan) {
+    switch (sweep_diag_mode()) {
+        case 0: launch_sweep<0>(bwd, grid, st, L, ld, winv, in, out, n, ctl, fault, vec, plan); break;
+        case 2: launch_sweep<2>(bwd, grid, st, L, ld, winv, in, out, n, ctl, fault, vec, plan); break;
+        default: launch_sweep<1>(bwd, grid, st, L, ld, winv, in, out, n, ctl, fault, vec, plan); break;
+    }
 }
 static bool panel_inv_mode() {
     static const bool inv = getenv("MADQP_CHOL_PANEL") && strcmp(getenv("MADQP_CHOL_PANEL"), "inv") == 0;
@@ -1616,20 +1799,29 @@ static bool mid_plan_build(madqp_chol* s, int nblk, int cap) {
     std::vector<uint32_t> w;
     s->mid_units = new (std::nothrow) int32_t[2 * nblk];
     if (!s->mid_units) return false;
+    // every failure exit leaves the handle without a plan AND without its pieces (the fallback schedule runs next: no
+    // sticky HIP error may reach its first launch check)
+    auto give_up = [&]() {
+        (void)hipGetLastError();
+        if (s->d_mid_plan) (void)hipFree(s->d_mid_plan);
+        s->d_mid_plan = nullptr;
+        delete[] s->mid_units;
+        s->mid_units = nullptr;
+        return false;
+    };
     for (int k = 0; k < nblk; ++k) {
         s->mid_units[nblk + k] = (int32_t)w.size();
         mid_plan_units(nblk, k, steps[k], w);
         s->mid_units[k] = (int32_t)w.size() - s->mid_units[nblk + k];
-        if (s->mid_units[k] != units[k]) return false;
+        if (s->mid_units[k] != units[k]) return give_up();
     }
     if (w.empty()) w.push_back(0);
     if (hipMalloc(&s->d_mid_plan, w.size() * sizeof(uint32_t)) != hipSuccess) {
-        (void)hipGetLastError();
         s->d_mid_plan = nullptr;
-        return false;
+        return give_up();
     }
     // (synchronous, pageable source: the copy has left `w` when the call returns; once per handle)
-    if (hipMemcpy(s->d_mid_plan, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemcpy(s->d_mid_plan, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return give_up();
     s->mid_plan_state = 1;
     return true;
 }
@@ -1978,14 +2170,7 @@ int32_t madqp_trsv_tile(madqp_ctx* ctx, int32_t trans, const double* L, int64_t 
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)tmp, 0x7FF8A5A5, 2 * (size_t)w, ctx->stream));
     const SweepPlan none{nullptr, nullptr, 0, 0};
     double* fault = ctx->d_res + MADQP_FAULT_SLOT;
-    if (!trans && sweep_refine())
-        hipLaunchKernelGGL(trsv_fwd_sweep_kernel<true>, dim3(nblk), dim3(1024), 0, ctx->stream, L, ld, winv, v, tmp, w, ctl, fault, vec, none);
-    else if (!trans)
-        hipLaunchKernelGGL(trsv_fwd_sweep_kernel<false>, dim3(nblk), dim3(1024), 0, ctx->stream, L, ld, winv, v, tmp, w, ctl, fault, vec, none);
-    else if (sweep_refine())
-        hipLaunchKernelGGL(trsv_bwd_sweep_kernel<true>, dim3(nblk), dim3(1024), 0, ctx->stream, L, ld, winv, v, tmp, w, ctl, fault, vec, none);
-    else
-        hipLaunchKernelGGL(trsv_bwd_sweep_kernel<false>, dim3(nblk), dim3(1024), 0, ctx->stream, L, ld, winv, v, tmp, w, ctl, fault, vec, none);
+    launch_sweep(trans != 0, nblk, ctx->stream, L, ld, winv, v, tmp, w, ctl, fault, vec, none);
     LAUNCH_CHECK(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(v, tmp, (size_t)w * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return MADQP_OK;
@@ -2012,12 +2197,7 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
         const SweepPlan pb{s->d_jobs, part_b, s->sweep_chunk, s->sweep_maxc};
         HIP_TRY(ctx, hipMemsetAsync(s->d_info + 1, 0, 3 * sizeof(int32_t), ctx->stream));
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)s->tmp, 0x7FF8A5A5, 2 * (size_t)s->tmp_len, ctx->stream));
-        if (sweep_refine())
-            hipLaunchKernelGGL(trsv_fwd_sweep_kernel<true>, dim3(grid), dim3(1024), 0, ctx->stream, A, lda, s->winv, rhs,
-                               s->tmp, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec, pf);
-        else
-            hipLaunchKernelGGL(trsv_fwd_sweep_kernel<false>, dim3(grid), dim3(1024), 0, ctx->stream, A, lda, s->winv, rhs,
-                               s->tmp, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec, pf);
+        launch_sweep(false, grid, ctx->stream, A, lda, s->winv, rhs, s->tmp, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec, pf);
         LAUNCH_CHECK(ctx);
         if (s->npos < n) {  // y <- diag(I, -I) y
             const int64_t len = n - s->npos;
@@ -2026,12 +2206,7 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
             LAUNCH_CHECK(ctx);
         }
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)rhs, 0x7FF8A5A5, 2 * (size_t)n, ctx->stream));
-        if (sweep_refine())
-            hipLaunchKernelGGL(trsv_bwd_sweep_kernel<true>, dim3(grid), dim3(1024), 0, ctx->stream, A, lda, s->winv, s->tmp,
-                               rhs, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec, pb);
-        else
-            hipLaunchKernelGGL(trsv_bwd_sweep_kernel<false>, dim3(grid), dim3(1024), 0, ctx->stream, A, lda, s->winv, s->tmp,
-                               rhs, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec, pb);
+        launch_sweep(true, grid, ctx->stream, A, lda, s->winv, s->tmp, rhs, n, s->d_info, ctx->d_res + MADQP_FAULT_SLOT, vec, pb);
         LAUNCH_CHECK(ctx);
     }
     return MADQP_OK;

@@ -506,7 +506,7 @@ extern "C" int32_t madqp_dist_create(madqp_ctx* ctx, int32_t rank, int32_t world
     static const int force = getenv("MADQP_DIST_FORCE_RCCL") ? atoi(getenv("MADQP_DIST_FORCE_RCCL")) : 0;
     const int32_t force_comm = (world == 1 && !ops && force) ? 1 : 0;
     madqp_dist* d = nullptr;
-    r = distcore::create(dev, rank, world, P, Q, n, nb, ops, force_comm, &d);
+    r = distcore::create(dev, rank, world, P, Q, n, nb, ops, force_comm, &d);  // sizes and this rank's verdict; no allocation yet
     if (r) {
         if (d) madqp_fail(ctx, r, "madqp_dist_create: %s", d->err);
         distcore::destroy(d);
@@ -545,6 +545,14 @@ extern "C" int32_t madqp_dist_create(madqp_ctx* ctx, int32_t rank, int32_t world
             madqp_dist_destroy(d);
             return MADQP_ERR_HIP;
         }
+    }
+    // the buffers: a COLLECTIVE decision (every rank fits and every allocation succeeded, or every rank refuses with
+    // MADQP_ERR_ALLOC) -- taken after the communicators exist, so that no rank waits in them for one that has left
+    r = distcore::allocate(d);
+    if (r) {
+        madqp_fail(ctx, r, "madqp_dist_create: %s", d->err);
+        madqp_dist_destroy(d);
+        return r;
     }
     *out = d;
     return MADQP_OK;

@@ -141,7 +141,10 @@ class DeviceQP:
 
     @classmethod
     def synthetic(cls, backend, seed: int, n: int, m: int, family: str = "wigner"):
-        """0 <= x <= 1, 0 <= Ax <= 1, x0 = 0; A ~ N(0,1), H Wigner + 3 I (or LP)."""
+        """0 <= x <= 1, 0 <= Ax <= 1, x0 = 0; A ~ N(0,1); H by family: "wigner" (Wigner + 3 I, O(n^2) to
+        generate: the large configs), "dummy" (H = G'G + 100 I with G n x n N(0,1) from the H stream -- R R' + 100 I of
+        MadNLPTests.DenseDummyQP, test/runtests.jl:9, with R = G': n_x <= ~10 000, one call of the library's own SYRK),
+        "lp" (no Hessian)."""
         dev = backend.device
         A = torch.empty((m, n), dtype=torch.float64, device=dev)
         backend.gen_normal(stream_key(seed, STREAM_A), 0, A)
@@ -151,6 +154,15 @@ class DeviceQP:
         if family == "wigner":
             H = torch.empty((n, n), dtype=torch.float64, device=dev)
             backend.gen_wigner(stream_key(seed, STREAM_H), n, 1.0 / math.sqrt(n), H)
+        elif family == "dummy":
+            G = torch.empty((n, n), dtype=torch.float64, device=dev)
+            backend.gen_normal(stream_key(seed, STREAM_H), 0, G)
+            H = torch.zeros((n, n), dtype=torch.float64, device=dev)
+            d = torch.full((n,), 100.0, dtype=torch.float64, device=dev)
+            # lower triangle of G'G + 100 I (column-major lower = row-major upper of the same symmetric matrix)
+            backend.syrk_assemble(n, n, G, n, None, None, n, d, H, n)
+            H = torch.triu(H) + torch.triu(H, 1).T
+            del G
         elif family != "lp":
             raise ValueError(family)
         z = lambda k, v: torch.full((k,), v, dtype=torch.float64, device=dev)

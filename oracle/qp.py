@@ -138,6 +138,9 @@ def synthetic_qp(seed: int, n: int, m: int, family: str = "wigner") -> DenseQP:
         H = gen_H_wigner(seed, n)
     elif family == "lp":
         H = np.zeros((n, n))
+    elif family == "dummy":  # R R' + 100 I of MadNLPTests.DenseDummyQP (test/runtests.jl:9), R = G'
+        G = gen_normal(stream_key(seed, STREAM_H), np.arange(n * n, dtype=U64)).reshape(n, n)
+        H = G.T @ G + 100.0 * np.eye(n)
     else:
         raise ValueError(family)
     return DenseQP(

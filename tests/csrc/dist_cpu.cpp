@@ -243,6 +243,7 @@ int32_t madqp_distcpu_create(int32_t rank, int32_t world, int32_t P, int32_t Q, 
     if (!out || (world > 1 && !ops)) return MADQP_ERR_ARG;
     Dev* dev = new Dev();
     int32_t r = distcore::create(dev, rank, world, P, Q, n, nb, ops, 0, out);
+    if (!r) r = distcore::allocate(*out);  // collective: every rank fits, or every rank refuses
     if (r) {
         if (*out) snprintf(g_last_error, sizeof(g_last_error), "%s", (*out)->err);
         distcore::destroy(*out);

@@ -162,3 +162,26 @@ def test_a_problem_that_does_not_fit_is_refused_before_anything_is_allocated(cpu
     assert "GB of device memory" in rec["err"] and "50.00 GB are free" in rec["err"], rec["err"]
     need = float(rec["err"].split(" needs ")[1].split(" GB")[0])
     assert 80.0 < need < 81.0, rec["err"]  # the 100 096^2 local matrix alone is 80.15 GB
+
+
+def test_the_memory_verdict_is_collective(cpuref, tmp_path):
+    """byte totals and free memory differ between ranks, and the refusal of a problem that does not
+    fit used to be each rank's own -- a rank that fitted went on into the communicator set-up and waited there for
+    ever.  Now create() only plans, and allocate() (after the communicators exist) takes ONE collective decision: here
+    only rank 1 of a 1 x 2 grid is short of memory, BOTH ranks must return MADQP_ERR_ALLOC -- rank 1 with its own
+    figures, rank 0 saying that another rank refused -- and the process group must be usable afterwards."""
+    out = str(tmp_path / "rec")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1",
+               MADQP_TEST_SMALL_RANK="1", MADQP_TEST_SMALL_BYTES="100000")
+    env.pop("MADQP_TEST_MEM_FREE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29571",
+           os.path.join(ROOT, "tests", "dist2d_refuse_worker.py"), out, "1", "2", "600", "128"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)  # (a hang is the failure this guards)
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = [json.load(open(f"{out}.{k}")) for k in range(2)]
+    for rec in recs:
+        assert rec["rc"] == -3 and not rec["handle"] and rec["comm_error"] is None, rec
+        assert rec["rc_again"] == 0, rec
+    assert "GB of device memory" in recs[1]["err"] and "are free" in recs[1]["err"], recs[1]["err"]
+    assert "other rank(s)" in recs[0]["err"] and "every rank refuses" in recs[0]["err"], recs[0]["err"]

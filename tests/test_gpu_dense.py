@@ -319,12 +319,14 @@ def test_symmetric_matvec_from_the_lower_triangle(hip, n, ld):
     hip.kkt_destroy(h)
 
 
-def test_refined_sweeps_option_leaves_the_residual_of_substitution():
-    """MADQP_SWEEP_REFINE=1 (chol.hip: trsv_*_sweep_kernel<true>, off by default): the diagonal step of both sweeps as
-    z = z0 + W (v - L_rr z0) instead of the product with the stored inverse alone.  On a matrix whose diagonal blocks are
-    ill conditioned the plain product leaves a residual of cond(L_rr) eps, the refined step the residual of a
-    substitution; both must solve the system, the refined one no worse -- and the panel solve is block substitution either
-    way (MADQP_CHOL_PANEL=inv: the 128 x 128 inverse product of rounds 1-3, for comparison)."""
+def test_sweeps_leave_the_residual_of_substitution():
+    """Round 5: the diagonal step of both sweeps is UNIT BLOCK SUBSTITUTION over the 16 x 16 sub-blocks with images
+    normalised once per factorisation (chol.hip: sweep_image_kernel, sweep_diag_fwd / _bwd) -- the default.  On a matrix
+    whose diagonal blocks are ill conditioned the product with the stored 128 x 128 inverse (rounds 1-4, kept as
+    MADQP_SWEEP_DIAG=inv) leaves a residual of cond(L_rr) eps; the default, and plain block substitution
+    (MADQP_SWEEP_DIAG=sub16, the A/B form), must leave the residual of a substitution -- backward stable.  The panel
+    solve is block substitution either way (MADQP_CHOL_PANEL=inv: the inverse products of rounds 1-3, for comparison;
+    its images are full inverses, so its sweeps multiply too)."""
     import json
     import os
     import subprocess
@@ -360,15 +362,17 @@ def test_refined_sweeps_option_leaves_the_residual_of_substitution():
         print(json.dumps(out))
     ''') % root
     res = {}
-    for name, env in (("plain", {}), ("refined", {"MADQP_SWEEP_REFINE": "1"}), ("inv_panel", {"MADQP_CHOL_PANEL": "inv"})):
+    for name, env in (("default", {}), ("sub16", {"MADQP_SWEEP_DIAG": "sub16"}), ("inv_sweeps", {"MADQP_SWEEP_DIAG": "inv"}),
+                      ("inv_panel", {"MADQP_CHOL_PANEL": "inv"})):
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         res[name] = json.loads(p.stdout.strip().splitlines()[-1])
     print("scaled residuals:", res)
     for n in ("300", "1000"):
-        assert res["plain"][n] < 1e-11 and res["inv_panel"][n] < 1e-11  # (all of them solve the system)
-        assert res["refined"][n] <= 4e-16 * int(n)                         # backward stable: the residual of substitution
-        assert res["refined"][n] <= res["plain"][n] * 1.5
+        assert res["inv_sweeps"][n] < 1e-11 and res["inv_panel"][n] < 1e-11  # (all of them solve the system)
+        for name in ("default", "sub16"):
+            assert res[name][n] <= 4e-16 * int(n), (name, n, res[name][n])  # backward stable: the residual of substitution
+            assert res[name][n] <= res["inv_sweeps"][n] * 1.5, (name, n)
 
 
 def test_mid_size_schedules_factor_the_same_matrix():

@@ -99,10 +99,55 @@ class BlockChol:
                 else:
                     x[a:b_] = Wj @ (v[a:b_] - Ljj[a:b_, :a] @ x[:a])
             return x
+        if self.sweep in ("nrm16", "dst16"):
+            return self._nsolve(Ljj, v, trans, self.sweep == "nrm16")
         A, Wm = (Ljj.T, W.T) if trans else (Ljj, W)
         x = Wm @ v
         if self.sweep.startswith("ref"):
             x = x + Wm @ (v - A @ x)
+        return x
+
+    @staticmethod
+    def _nsolve(Ljj, v, trans, proper, g=16):
+        """UNIT block substitution with images normalised by the g x g diagonal inverses, formed once in fp64 (what a
+        device kernel would store per 128-block): forward image Lt_IJ = L_IJ W_JJ (column-normalised: u_I = v_I - sum
+        Lt_IJ u_J, z_I = W_II u_I), backward image Lh_IJ = W_II L_IJ (row-normalised: w_J = v_J - sum Lh_IJ' w_I,
+        x_J = W_JJ' w_J).  proper=False ("dst16"): the forward sweep with the ROW-normalised image (z_I = W_II v_I - sum
+        Lh_IJ z_J) and the backward sweep with the COLUMN-normalised one -- W distributed over the sum."""
+        w = Ljj.shape[0]
+        blocks = [(a, min(w, a + g)) for a in range(0, w, g)]
+        Wd = [sla.solve_triangular(Ljj[a:b, a:b], np.eye(b - a), lower=True) for a, b in blocks]
+        x = np.zeros(w)
+        col = (not trans) == proper  # which normalisation this sweep uses
+        nb_ = len(blocks)
+        img = {}
+        for I, (a, b) in enumerate(blocks):
+            for J, (c, d) in enumerate(blocks[:I]):
+                img[I, J] = (Ljj[a:b, c:d] @ Wd[J]) if col else (Wd[I] @ Ljj[a:b, c:d])
+        if not trans:
+            for I, (a, b) in enumerate(blocks):
+                if col:   # u_I = v_I - sum Lt_IJ u_J ; x holds u, scaled at the end of its step
+                    x[a:b] = v[a:b] - sum((img[I, J] @ x[blocks[J][0]:blocks[J][1]] for J in range(I)), np.zeros(b - a))
+                else:     # z_I = W_II v_I - sum Lh_IJ z_J
+                    x[a:b] = Wd[I] @ v[a:b] - sum((img[I, J] @ x[blocks[J][0]:blocks[J][1]] for J in range(I)), np.zeros(b - a))
+            if col:
+                u = x.copy()
+                for I, (a, b) in enumerate(blocks):
+                    x[a:b] = Wd[I] @ u[a:b]
+                # (the updates above must use u, not z: redo with u kept separately)
+                u = np.zeros(w)
+                for I, (a, b) in enumerate(blocks):
+                    u[a:b] = v[a:b] - sum((img[I, J] @ u[blocks[J][0]:blocks[J][1]] for J in range(I)), np.zeros(b - a))
+                    x[a:b] = Wd[I] @ u[a:b]
+            return x
+        wv = np.zeros(w)
+        for J in range(nb_ - 1, -1, -1):
+            c, d = blocks[J]
+            if not col:   # row-normalised image, proper backward: w_J = v_J - sum Lh_IJ' w_I ; x_J = W_JJ' w_J
+                wv[c:d] = v[c:d] - sum((img[I, J].T @ wv[blocks[I][0]:blocks[I][1]] for I in range(J + 1, nb_)), np.zeros(d - c))
+                x[c:d] = Wd[J].T @ wv[c:d]
+            else:         # column-normalised image: x_J = W_JJ' v_J - sum Lt_IJ' x_I
+                x[c:d] = Wd[J].T @ v[c:d] - sum((img[I, J].T @ x[blocks[I][0]:blocks[I][1]] for I in range(J + 1, nb_)), np.zeros(d - c))
         return x
 
     def solve(self, rhs):
