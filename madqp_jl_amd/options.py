@@ -52,11 +52,23 @@ class IPMOptions:
         fixed_variable_treatment=None,
         driver="python",  # "python": this package drives each kernel; "native": one C call per iteration
         # extension (0 = the reference's solve_system!, src/linear_solver.jl:19-45): steps of iterative refinement with the
-        # residual that solve_system! forms anyway.  The explicit 128 x 128 block inverses of the device factorisation
-        # cost a little backward stability against LAPACK's substitutions on problems at the edge of fp64 (LPs through
-        # the condensed form); one step more than makes up for it (+1 solve and +1 mul! per solve)
-        refine_steps=0,
+        # residual that solve_system! forms anyway (+1 solve and +1 mul! per solve and step).  The device factorisation
+        # multiplies with explicit inverses of 16 x 16 sub-blocks (diagonal kernel, panel solve, sweeps) where LAPACK
+        # substitutes scalar by scalar; on small ill-conditioned problems that shows in the per-iteration traces (tens of
+        # times the CPU noise floor on the random soak problems of order <= 260), and one step removes
+        # it (0 of 398 cases beyond the floor).  None (default) = AUTO: one step while the factorised matrix has order
+        # <= REFINE_AUTO_MAX -- where a solve costs microseconds -- and none above, where the 16-blocked arithmetic is
+        # what LAPACK's own blocked kernels do and the larger parity cases sit within the stated bar without it.
+        refine_steps=None,
     )
+    REFINE_AUTO_MAX = 1024  # MADQP_REFINE_AUTO_MAX overrides
+
+    @staticmethod
+    def refine_auto(order: int) -> int:
+        """refine_steps of the AUTO rule for a factorised matrix of this order"""
+        import os
+
+        return 1 if order <= int(os.environ.get("MADQP_REFINE_AUTO_MAX", IPMOptions.REFINE_AUTO_MAX)) else 0
 
     def __init__(self, **kw):
         for k, v in self._DEFAULTS.items():

@@ -67,7 +67,7 @@ def native_options(opt) -> CMpcOptions:
     rule, reg = opt.step_rule, opt.regularization
     c = CMpcOptions(tol=opt.tol, max_iter=opt.max_iter, max_ncorr=opt.max_ncorr, mu_min=opt.mu_min,
                     check_residual=int(bool(opt.check_residual)), tol_linear_solve=opt.tol_linear_solve,
-                    refine_steps=int(opt.refine_steps))
+                    refine_steps=int(opt.refine_steps or 0))  # (None: AUTO, resolved by MPCSolver; the batched engine does not refine)
     if isinstance(rule, ConservativeStep):
         c.step_rule, c.step_param = 0, rule.tau
     elif isinstance(rule, AdaptiveStep):
@@ -128,6 +128,9 @@ class MPCSolver:
                 isinstance(reg, NoRegularization) or reg.delta_d >= 0.0):
             raise ValueError("the condensed KKT system needs dual regularization delta_d < 0 "
                              "when the problem has equality constraints")
+        if self.opt.refine_steps is None:  # AUTO (options.py): by the order of the matrix that is factorised
+            order = {"condensed": self.nx, "normal": self.m}.get(self.opt.kkt_system, self.nx + self.m)
+            self.opt.refine_steps = IPMOptions.refine_auto(order)
         self.obj_scale, self.con_scale = 1.0, None
         self.H, self.A, self.q = qp.H, qp.A, qp.q  # replaced by scaled copies if scaling != 1
         self.kkt = None

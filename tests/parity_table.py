@@ -84,7 +84,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--soak-count", type=int, default=1000, help="cases per soak stream")
-    ap.add_argument("--refine", default="0", help="device refine_steps settings to run, comma separated")
+    ap.add_argument("--refine", default="auto", help="device refine_steps settings to run, comma separated (auto = the default rule)")
     ap.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1))
     a = ap.parse_args()
     import madqp_jl_amd as M
@@ -116,8 +116,8 @@ def main():
         row = dict(case=name, n=int(qp.nvar), m=int(qp.ncon), lp=qp.H is None or not np.any(qp.H), iter_ref=c["ref"]["iter"],
                    floor_dx=c["floor"]["dx"], floor2_dx=c["floor2"]["dx"],
                    ensemble_stopped_elsewhere=c["floor"]["stopped_elsewhere"])
-        for rs in [int(x) for x in a.refine.split(",")]:
-            s = M.MPCSolver(dq, be, regularization=REG, driver="native", refine_steps=rs, **opts)
+        for rs in a.refine.split(","):  # "auto": the library's default rule (options.py: one step up to order 1024)
+            s = M.MPCSolver(dq, be, regularization=REG, driver="native", refine_steps=None if rs == "auto" else int(rs), **opts)
             r = s.solve()
             s.close()
             key = f"refine{rs}"
@@ -138,9 +138,10 @@ def main():
 
     out = dict(what="device (native driver) distance from the LAPACK oracle in units of the CPU noise floor; 0 = within the "
                     "stated bar", library_panel=os.environ.get("MADQP_CHOL_PANEL", "sub16"),
+               library_sweep_diag=os.environ.get("MADQP_SWEEP_DIAG", "nrm16"),
                summary={f"refine{rs}": dict(vs_ensemble=summary(f"refine{rs}", "vs_ensemble"),
                                             vs_two_runs=summary(f"refine{rs}", "vs_two_runs"))
-                        for rs in [int(x) for x in a.refine.split(",")]},
+                        for rs in a.refine.split(",")},
                rows=rows)
     txt = json.dumps(out, indent=1, default=float)
     if a.out:

@@ -178,6 +178,30 @@ def test_gpus_2_without_a_launcher_is_a_run_on_two_ranks():
     assert "starting -m torch.distributed.run" in p.stderr
 
 
+def test_the_drivers_n8_command_is_one_line_on_the_2x4_grid():
+    """the one run nobody can rehearse on hardware -- the driver's exact N = 8 form, `python bench.py
+    --gpus 8 --steps 20 --warmup 5` (plus a reduced size: this is the scaffolding, not the arithmetic) -- on eight gloo
+    ranks of the CPU test double: ONE line, n_gpus 8, the 2 x 4 grid of BASELINE configs[4], communicator sizes 8 / 4 / 2,
+    `roofline` present, the independent-QPs leg beside it.  (Eight processes may not share one GPU on this pool -- the box
+    allows six -- so the GPU rehearsal, tests/test_gpu_bench.py, runs four ranks on a 2 x 2 grid.)"""
+    import json
+
+    p = _run_bench(["--gpus", "8", "--steps", "20", "--warmup", "5", "--nx", "48", "--m", "20", "--driver", "python",
+                    "--no-cpu-baseline", "--extra-timeout", "240"], {"MADQP_BENCH_TEST_DOUBLE": "bench_double:Double"},
+                   timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["n_gpus_requested"] == 8 and out["scaling"] == "strong"
+    assert out["steps"] == 20 and out["warmup"] == 5 and out["value"] > 0
+    assert out["distributed"]["grid"] == [2, 4] and out["config"]["parallelism"].startswith("grid 2x4")
+    comm = out["comm"]
+    assert (comm["world_size"], comm["row_comm_size"], comm["col_comm_size"]) == (8, 4, 2), comm
+    assert out["roofline"]["bound"] == "mfma" and "job_fraction_of_peak" in out["roofline"]
+    assert out["independent_qps"]["value"] > 0 and out["ranks"]["world_size"] == 8
+
+
 def test_world_size_that_differs_from_gpus_is_refused_without_a_line():
     for gpus, env in (("2", {"WORLD_SIZE": "1", "RANK": "0"}), ("2", {"WORLD_SIZE": "4", "RANK": "0"}),
                       ("1", {"WORLD_SIZE": "2", "RANK": "1"})):

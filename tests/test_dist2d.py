@@ -85,11 +85,20 @@ def check_lookahead_order(schedule, p, q, P, Q, T):
     (1, 3, 900, 128, 3, 29559),   # one process row of three: whole-panel factorisation, operands gathered locally
     (4, 1, 800, 128, 2, 29561),   # one process column of four: row operands read in place, column operands stored
 ])
-def test_distributed_cholesky_2d(cpuref, tmp_path, P, Q, n, nb, group, port):
+@pytest.mark.parametrize("bcast", ["collective", "p2p"])
+def test_distributed_cholesky_2d(cpuref, tmp_path, P, Q, n, nb, group, port, bcast):
+    """`bcast`: every broadcast of the schedule as the library collective (ncclBroadcast in the product; default) or as ONE
+    group of point-to-point transfers from the root to each peer of the process row / column / world
+    (MADQP_DIST_BCAST=p2p, csrc/dist_core.inc::comm_bcast_p2p: separate xGMI links instead of a ring, SURVEY.md 8e) -- the
+    same schedule, the same buffers, the same results on all eleven grids."""
     world = P * Q
     out = str(tmp_path / "rec")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
     env.pop("MADQP_DIST_GROUP", None)
+    env.pop("MADQP_DIST_BCAST", None)
+    if bcast == "p2p":
+        env["MADQP_DIST_BCAST"] = "p2p"
+        port += 100
     if group:
         env["MADQP_DIST_GROUP"] = str(group)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
@@ -129,8 +138,12 @@ def test_distributed_cholesky_2d(cpuref, tmp_path, P, Q, n, nb, group, port):
     # solves: 2 collectives per GROUP and sweep (one reduce of the group's partial sums, one broadcast of its solution)
     G = min(group or max(1, 4096 // nb), T)
     NG = (T + G - 1) // G
-    if world > 1:
+    if world > 1 and bcast == "collective":
         assert all(rec["solve_calls"] == {"reduce": 2 * NG, "bcast": 2 * NG} for rec in recs), recs[0]["solve_calls"]
+    elif world > 1:  # the solved rows of a group travel point to point: no broadcast call at all, anywhere in the run
+        assert all(rec["solve_calls"] == {"reduce": 2 * NG, "bcast": 0} for rec in recs), recs[0]["solve_calls"]
+        assert all(rec["calls"]["bcast"] == 0 for rec in recs) and sum(rec["calls"]["send"] for rec in recs) > 0
+        assert sum(rec["calls"]["send"] for rec in recs) == sum(rec["calls"]["recv"] for rec in recs)
     # volume: a rank receives each panel tile at most once per operand role; as roots the ranks send
     # (P > 1) T diagonal images + (Q > 1) the row operands + (P > 1) the transposed operands -- never the matrix twice
     total = sum(rec["bytes_sent"] for rec in recs)

@@ -99,12 +99,19 @@ def test_kkt_grid_on_one_gpu(tmp_path, P, Q, nb, port):
     assert sum(rec["bytes_sent"] for rec in recs) > 0
 
 
-def test_rccl_calls_with_one_rank(tmp_path):
+@pytest.mark.parametrize("bcast", ["collective", "p2p"])
+def test_rccl_calls_with_one_rank(tmp_path, bcast):
     """The RCCL side of dist.hip -- run-time binding to the process's librccl, ncclCommInitRank, two ncclCommSplit,
     every ncclBroadcast / ncclReduce / ncclAllReduce of the schedule on the internal streams -- cannot meet a second
-    rank on a one-GPU box; MADQP_DIST_FORCE_RCCL=1 makes a single rank go through all of it (groups of one)."""
+    rank on a one-GPU box; MADQP_DIST_FORCE_RCCL=1 makes a single rank go through all of it (groups of one).
+    bcast = "p2p" (MADQP_DIST_BCAST): every broadcast image instead travels to the rank itself through a grouped
+    ncclSend / ncclRecv pair (dist_core.inc::comm_bcast) -- the point-to-point form of the broadcasts, on real RCCL calls;
+    the collective set-up verdict of distcore::allocate (an all-reduce on a scratch word) runs in both."""
     out = str(tmp_path / "rec")
     env = dict(os.environ, MADQP_DIST_FORCE_RCCL="1")
+    env.pop("MADQP_DIST_BCAST", None)
+    if bcast == "p2p":
+        env["MADQP_DIST_BCAST"] = "p2p"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist2d_kkt_worker.py"), out, "1", "1", "256"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])

@@ -7,6 +7,9 @@ acceptance rule of tests/parity.py: identical iteration counts, except threshold
 objective to 1e-9 (relative) and solution to 1e-7 (the stated bar), or SENS_FACTOR = 4 x the noise floor
 measured over an ensemble of valid CPU executions of the oracle (tests/parity.py: ensemble_floor) where the problem's
 conditioning does not support the bar (round 2 had 1e-7 / 1e-5 for every problem here, round 3 16 x a two-run distance).
+Round 5: the PER-ITERATION traces (alpha_p, alpha_d, inf_pr, inf_du, inf_compl, mu) are held to the same rule for the
+native and python drivers -- with the default library: sweeps that substitute and the AUTO refinement rule of
+madqp_jl_amd/options.py (every problem here has order <= 260).
 """
 import numpy as np
 import pytest
@@ -63,9 +66,13 @@ def run_case(hip, seed, n, m, lp, drivers):
             continue
         from parity import ensemble_floor, exceeds_stated_bar
 
-        if exceeds_stated_bar(r, ref, trace=False) and not floor:
+        # round 5: the per-iteration traces are compared too (native and python drivers; the batched engine keeps no trace):
+        # SURVEY.md 8d states the tolerance per iteration, and round 4's soak passed only because it looked at x and the
+        # objective
+        trace = name != "batched"
+        if exceeds_stated_bar(r, ref, trace=trace) and not floor:
             floor.update(ensemble_floor(qp, ref, regularization=OREG))
-        assert_parity(r, ref, qp, what, trace=False, floor=floor or None, regularization=OREG)
+        assert_parity(r, ref, qp, what, trace=trace, floor=floor or None, regularization=OREG)
     return ties
 
 

@@ -271,9 +271,22 @@ def cases(which):
                     yield f"soak{seed0 + t}", Q.random_qp(seed0 + t, n, m, lp), {}
 
 
+def small_cases(nmax=64):
+    """the soak streams' problems of order <= nmax, LPs and QPs: the whole matrix is one or a few 16 x 16 sub-blocks, so
+    the diagonal step's own arithmetic (inverse product against substitution INSIDE a sub-block) is what shows"""
+    for seed0, count in ((9000, 200), (1000, 150)):
+        rng = np.random.default_rng(seed0)
+        for t in range(count):
+            n = int(rng.integers(1, 260))
+            m = int(rng.integers(0, max(1, n)))
+            lp = bool(rng.integers(0, 4) == 0)
+            if n <= nmax:
+                yield f"soak{seed0 + t}", Q.random_qp(seed0 + t, n, m, lp), {}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", default="dist", choices=("dist", "soak", "all"))
+    ap.add_argument("--cases", default="dist", choices=("dist", "soak", "all", "small"))
     ap.add_argument("--ensemble", action="store_true", help="ratios against the three-execution noise floor")
     ap.add_argument("--variants", default="inv/inv,sub/inv,inv/sub,sub/sub,ref/inv,inv/ref,ref/ref,sub/ref")
     a = ap.parse_args()
@@ -281,7 +294,7 @@ def main():
     print("case".ljust(16) + "".join(f"{p + '/' + s:>22}" for p, s in variants) + "    (trace ratio | dx ratio | iterations if they differ)")
     worst = {v: 0.0 for v in variants}
     mism = {v: 0 for v in variants}
-    for name, qp, opts in cases(a.cases):
+    for name, qp, opts in (small_cases() if a.cases == "small" else cases(a.cases)):
         ref, ref2 = run(qp, None, **opts), run(qp, None, refine_steps=1, **opts)
         row = name.ljust(16)
         if a.ensemble:
