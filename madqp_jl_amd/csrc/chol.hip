@@ -1055,322 +1055,6 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
     if (64 + lane < w) st_sc1_f64(x + col0 + 64 + lane, z.y);
 }
 
-// ---- sweeps with a CHAIN WORKGROUP (round 5) ----------------------------------------------------------------------
-// In the kernels above every 128-row block is a hop between two workgroups: publish 128 values through L2, the next
-// block's workgroup polls them (~1 us), adds its last tile, reduces over its 16 waves and only then runs its diagonal
-// step -- 2.6 us per block with the inverse product of rounds 1-4, 4.1 us with the substitution of round 5, and 40 hops
-// of that are a whole sweep at n = 5 000.  Here ONE workgroup (the first ticket) walks the chain: block t needs, besides
-// its diagonal step, the products with the TWO nearest solved blocks (t-1, t-2) -- it keeps those tiles itself, fetched
-// one block ahead -- and the sum over all farther blocks (<= t-3), which helper workgroups (one job per <= `chunk` tiles
-// of a block row, ticket order) stream exactly as before and publish as 128 partial sums; a block's partial sums are
-// due two block times after the last solution they need is published, so the chain never waits for a hand-off:
-//     per block:  barrier | 12 waves: near-tile products with z_{t-1}, z_{t-2} from LDS | barrier |
-//                 wave 0: v = (b - far sums) - near sums, the diagonal step (unit block substitution), z_t -> LDS + L2
-//                 meanwhile waves 1..15: near tiles and the diagonal image of block t+1, far sums of block t+1
-// Forward and backward sweeps are the same chain program: the backward one reads the near tiles TRANSPOSED (copies made
-// once per factorisation by sweep_image_kernel: near[r][d] = (L_{r+1+d, r})'), so both are row-oriented products.
-// Every sum has a fixed order (wave order over the near products, chunk order over the far sums): results do not depend
-// on timing.  Progress: the chain workgroup holds ticket 0; a helper of block t needs solutions <= t-3, i.e. only helpers
-// with smaller tickets -- resident or finished, whatever the dispatch order and however few workgroups fit on the chip.
-constexpr int CH_TW = 12;                      // waves 1 .. CH_TW hold the near tiles: 11 columns each
-constexpr int CH_TC = 11;
-constexpr int CH_LDS_DOUBLES = 2 * XIMG_DOUBLES + CH_TW * NB + 2 * NB + NB;  // images (double buffered), red, zs ring, pre
-constexpr int HELP_LDS_DOUBLES = 2 * NB + 16 * NB + NB + NB * 65;            // xs, red, vs, colred (backward helpers)
-static_assert(CH_LDS_DOUBLES * 8 + 64 <= 160 * 1024, "the chain workgroup's LDS");
-static_assert(HELP_LDS_DOUBLES <= CH_LDS_DOUBLES, "helpers carve their arrays out of the same pool");
-
-struct ChainArgs {
-    const double* L;       // the factor (column-major, lda >= padded order, 16-byte aligned)
-    int64_t lda;
-    const double* winv;    // sweep images: block r at r*WBLK (forward) / + NB*NB (backward)
-    const double* near;    // backward only: block r: (L_{r+1,r})' at (2r)*NB*NB, (L_{r+2,r})' at (2r+1)*NB*NB
-    const double* b;       // right-hand side (n)
-    double* out;           // solution (n, sentinel filled): also the hand-off vector the helpers poll
-    int64_t n;
-    int32_t* ctl;          // ticket counter at ctl[slot]
-    int32_t slot;
-    double* fault;
-    const int32_t* jobs;   // ticket - 1 -> t | c << 20 (chain order, blocks t >= 3)
-    double* part;          // partial sums of job (t, c) at (t*maxc + c)*NB
-    int32_t chunk, maxc;
-};
-
-// stage the packed diagonal image of one block: waves 1..15 (tp = tid - 64 in [0, 960)), loads first, then the stores
-template <bool BWD>
-__device__ __forceinline__ void chain_stage_image(const double* __restrict__ G, double* __restrict__ X, int tp) {
-    double v[14];
-    int n_ld = 0;
-#pragma unroll
-    for (int B = 0; B < 8; ++B) {
-        const int len = BWD ? 16 * (B + 1) : NB - 16 * B, cnt = 16 * len;
-#pragma unroll
-        for (int e0 = 0; e0 < cnt; e0 += 960) {
-            const int e = e0 + tp, ec = e < cnt ? e : cnt - 1;  // (clamped: an unconditional load from an address that exists)
-            const int ck = ec / len, rr = ec - ck * len;
-            v[n_ld++] = G[(16 * B + ck) * NB + (BWD ? rr : 16 * B + rr)];
-        }
-    }
-    n_ld = 0;
-#pragma unroll
-    for (int B = 0; B < 8; ++B) {
-        const int len = BWD ? 16 * (B + 1) : NB - 16 * B, cnt = 16 * len;
-        const int base = BWD ? ximg_b_col(B) : ximg_f_col(B);
-#pragma unroll
-        for (int e0 = 0; e0 < cnt; e0 += 960) {
-            const int e = e0 + tp;
-            if (e < cnt) X[base + e] = v[n_ld];
-            ++n_ld;
-        }
-    }
-}
-
-template <bool BWD, int DIAG>
-__device__ __forceinline__ void sweep_chain_role(const ChainArgs& a, double* __restrict__ lds) {
-    double* ximg = lds;                             // [2][XIMG_DOUBLES]
-    double* red = lds + 2 * XIMG_DOUBLES;           // [CH_TW][NB]
-    double* zs = red + CH_TW * NB;                  // [2][NB]: z_t at zs[(t & 1) * NB]
-    double* pre = zs + 2 * NB;                      // [NB]: b - far sums of the current block
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t n = a.n, lda = a.lda;
-    const int nblk = (int)((n + NB - 1) / NB);
-    const bool tilew = wave >= 1 && wave <= CH_TW;
-    const int c0 = (wave - 1) * CH_TC;              // this wave's near-tile columns c0 .. c0 + 10 (clipped to 127)
-    auto blk = [&](int t) { return BWD ? nblk - 1 - t : t; };
-    // near tile of block t with source block t - 1 - d: rows 2 lane, 2 lane + 1 of the wave's columns; zero where it does
-    // not exist (t - 1 - d < 0), rows at or beyond n masked
-    auto load_near = [&](int t, int d, double2_t (&T)[CH_TC]) {
-        const bool have = tilew && t < nblk && t - 1 - d >= 0;
-        const int r = blk(have ? t : 0), src = blk(have ? t - 1 - d : 0);
-        const double* base = BWD ? a.near + ((int64_t)r * 2 + d) * NB * NB + 2 * lane
-                                 : a.L + (int64_t)r * NB + 2 * lane + (int64_t)src * NB * lda;
-        const int64_t ld = BWD ? NB : lda;
-        const int64_t row = (int64_t)r * NB + 2 * lane;
-        const bool ok0 = have && row < n, ok1 = have && row + 1 < n;
-#pragma unroll
-        for (int q = 0; q < CH_TC; ++q) {
-            const int c = (c0 + q < NB) ? c0 + q : NB - 1;
-            const double2_t v = *reinterpret_cast<const double2_t*>(base + (int64_t)(tilew ? c : 0) * ld);
-            T[q].x = (ok0 && c0 + q < NB) ? v.x : 0.0;
-            T[q].y = (ok1 && c0 + q < NB) ? v.y : 0.0;
-        }
-    };
-    // wave 13: b - (far sums of block t) for its two entries per lane, far sums in chunk order
-    auto far_sums = [&](int t, double& p0, double& p1) {
-        p0 = p1 = 0.0;
-        if (t >= nblk) return;
-        const int r = blk(t);
-        const int64_t i0 = (int64_t)r * NB + lane, i1 = i0 + 64;
-        const double b0 = i0 < n ? a.b[i0] : 0.0, b1 = i1 < n ? a.b[i1] : 0.0;
-        double f0 = 0.0, f1 = 0.0;
-        const int nc = t >= 3 ? (t - 2 + a.chunk - 1) / a.chunk : 0;
-        const double* pp = a.part + (int64_t)t * a.maxc * NB;
-        for (int cb = 0; cb < nc; cb += 8) {  // eight chunks' loads in flight at once (one L2 round trip, not sixteen)
-            unsigned long long u[8][2];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int c = cb + q < nc ? cb + q : nc - 1;
-                u[q][0] = ld_sc1_u64(pp + (int64_t)c * NB + lane);
-                u[q][1] = ld_sc1_u64(pp + (int64_t)c * NB + 64 + lane);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (cb + q < nc) {  // (added in chunk order; a slot still holding the sentinel is polled until it is filled)
-                    const double* pc = pp + (int64_t)(cb + q) * NB;
-                    f0 += (u[q][0] == SWEEP_SENTINEL) ? sweep_poll_one(pc + lane, a.fault) : __longlong_as_double(u[q][0]);
-                    f1 += (u[q][1] == SWEEP_SENTINEL) ? sweep_poll_one(pc + 64 + lane, a.fault) : __longlong_as_double(u[q][1]);
-                }
-            }
-        }
-        p0 = i0 < n ? b0 - f0 : 0.0;
-        p1 = i1 < n ? b1 - f1 : 0.0;
-    };
-    double2_t T1[CH_TC], T2[CH_TC];
-    double p0 = 0.0, p1 = 0.0;
-    // prologue: what phase 2 of block "-1" would have prepared
-    load_near(0, 0, T1);
-    load_near(0, 1, T2);
-    if (wave >= 1) chain_stage_image<BWD>(a.winv + (int64_t)blk(0) * WBLK + (BWD ? NB * NB : 0), ximg, tid - 64);
-    if (wave == 13) far_sums(0, p0, p1);
-    if (tid < 2 * NB) zs[tid] = 0.0;
-    for (int t = 0; t < nblk; ++t) {
-        __syncthreads();  // A: z_{t-1} (and image t, staged during block t-1) are in LDS
-        if (tilew) {
-            const double* z1 = zs + ((t - 1) & 1) * NB + c0;  // z_{t-1}
-            const double* z2 = zs + (t & 1) * NB + c0;        // z_{t-2}
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int q = 0; q < CH_TC; ++q) {
-                const int cq = (c0 + q < NB) ? q : 0;  // (clipped columns carry zero tiles)
-                const double x1 = z1[cq], x2 = z2[cq];
-                a0 = __builtin_fma(T1[q].x, x1, a0);
-                a1 = __builtin_fma(T1[q].y, x1, a1);
-                a0 = __builtin_fma(T2[q].x, x2, a0);
-                a1 = __builtin_fma(T2[q].y, x2, a1);
-            }
-            red[(wave - 1) * NB + 2 * lane] = a0;
-            red[(wave - 1) * NB + 2 * lane + 1] = a1;
-        } else if (wave == 13) {
-            pre[lane] = p0;
-            pre[64 + lane] = p1;
-        }
-        __syncthreads();  // B: near sums and far sums of block t are in LDS
-        if (wave == 0) {
-            double u0 = pre[lane], u1 = pre[64 + lane];
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int w = 0; w < CH_TW; ++w) {
-                s0 += red[w * NB + lane];
-                s1 += red[w * NB + 64 + lane];
-            }
-            u0 -= s0;
-            u1 -= s1;
-            const double* X = ximg + (t & 1) * XIMG_DOUBLES;
-            const double2_t z = BWD ? sweep_diag_bwd<DIAG>(X, pre, lane, u0, u1) : sweep_diag_fwd<DIAG>(X, pre, lane, u0, u1);
-            const int r = blk(t);
-            const int64_t i0 = (int64_t)r * NB + lane, i1 = i0 + 64;
-            const double z0 = i0 < n ? z.x : 0.0, z1v = i1 < n ? z.y : 0.0;
-            zs[(t & 1) * NB + lane] = z0;
-            zs[(t & 1) * NB + 64 + lane] = z1v;
-            if (i0 < n) st_sc1_f64(a.out + i0, z0);
-            if (i1 < n) st_sc1_f64(a.out + i1, z1v);
-        } else {
-            // block t + 1: its near tiles (sources t and t - 1), its diagonal image, its far sums
-            load_near(t + 1, 0, T1);
-            load_near(t + 1, 1, T2);
-            if (t + 1 < nblk)
-                chain_stage_image<BWD>(a.winv + (int64_t)blk(t + 1) * WBLK + (BWD ? NB * NB : 0), ximg + ((t + 1) & 1) * XIMG_DOUBLES,
-                                       tid - 64);
-            if (wave == 13) far_sums(t + 1, p0, p1);
-        }
-    }
-}
-
-// helper job (t, c): the far tiles s0 .. s1-1 of block t (sources <= t - 3), 128 partial sums published to part
-__device__ __forceinline__ void sweep_helper_fwd(const ChainArgs& a, double* __restrict__ lds, int t, int c) {
-    double* xs = lds;                 // [2][NB]
-    double* red = lds + 2 * NB;       // [16][NB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t n = a.n, lda = a.lda;
-    const int j0 = c * a.chunk, j1 = (j0 + a.chunk < t - 2) ? j0 + a.chunk : t - 2;
-    const int64_t row0 = (int64_t)t * NB;
-    const bool ok0 = row0 + 2 * lane < n, ok1 = row0 + 2 * lane + 1 < n;
-    double a0 = 0.0, a1 = 0.0;
-    const double* Lr = a.L + row0 + 2 * lane + (int64_t)(wave * 4) * lda;
-    double2_t A[4], B[4];
-    sweep_load_half(Lr + (int64_t)j0 * NB * lda, lda, ok0, ok1, true, A);
-    for (int j = j0; j < j1; ++j) {
-        const double* Tj = Lr + (int64_t)j * NB * lda;
-        sweep_load_half(Tj + 64 * lda, lda, ok0, ok1, true, B);
-        if (wave == 0) sweep_poll_block(a.out, j, n, xs + (j & 1) * NB, a.fault, lane);
-        __syncthreads();
-        const double* xj = xs + (j & 1) * NB;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double xv = xj[wave * 4 + q];
-            a0 = __builtin_fma(A[q].x, xv, a0);
-            a1 = __builtin_fma(A[q].y, xv, a1);
-        }
-        if (j + 1 < j1) sweep_load_half(Tj + (int64_t)NB * lda, lda, ok0, ok1, true, A);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double xv = xj[64 + wave * 4 + q];
-            a0 = __builtin_fma(B[q].x, xv, a0);
-            a1 = __builtin_fma(B[q].y, xv, a1);
-        }
-    }
-    red[wave * NB + 2 * lane] = a0;
-    red[wave * NB + 2 * lane + 1] = a1;
-    __syncthreads();
-    if (tid < NB) {
-        double sum = red[tid];
-#pragma unroll
-        for (int q = 1; q < 16; ++q) sum += red[q * NB + tid];
-        st_sc1_f64(a.part + ((int64_t)t * a.maxc + c) * NB + tid, sum);
-    }
-}
-__device__ __forceinline__ void sweep_helper_bwd(const ChainArgs& a, double* __restrict__ lds, int t, int c) {
-    double* xs = lds;                      // [2][NB]
-    double* vs = lds + 2 * NB + 16 * NB;   // [NB]
-    double* colred = vs + NB;              // [NB][65]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t n = a.n, lda = a.lda;
-    const int nblk = (int)((n + NB - 1) / NB);
-    const int r = nblk - 1 - t;
-    const int s0 = c * a.chunk, s1 = (s0 + a.chunk < t - 2) ? s0 + a.chunk : t - 2;  // sources nblk-1-s, s in [s0, s1)
-    const int64_t col0 = (int64_t)r * NB;
-    double acc[2][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[h][q] = 0.0;
-    const double* Lc = a.L + 2 * lane + (col0 + wave * 4) * lda;  // + row block offset
-    double2_t A[4], B[4];
-    auto rows_ok = [&](int j, bool& o0, bool& o1) {
-        const int64_t i0 = (int64_t)j * NB + 2 * lane;
-        o0 = i0 < n;
-        o1 = i0 + 1 < n;
-    };
-    const int jhi = nblk - 1 - s0, jlo = nblk - 1 - s1;  // row blocks jhi, jhi-1, .., jlo+1
-    {
-        bool o0, o1;
-        rows_ok(jhi, o0, o1);
-        sweep_load_half(Lc + (int64_t)jhi * NB, lda, o0, o1, true, A);
-    }
-    for (int j = jhi; j > jlo; --j) {
-        bool o0, o1;
-        rows_ok(j, o0, o1);
-        const double* Tj = Lc + (int64_t)j * NB;
-        sweep_load_half(Tj + 64 * lda, lda, o0, o1, true, B);
-        if (wave == 0) sweep_poll_block(a.out, j, n, xs + (j & 1) * NB, a.fault, lane);
-        __syncthreads();
-        const double x0 = xs[(j & 1) * NB + 2 * lane], x1 = xs[(j & 1) * NB + 2 * lane + 1];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[0][q] = __builtin_fma(A[q].y, x1, __builtin_fma(A[q].x, x0, acc[0][q]));
-        if (j - 1 > jlo) {
-            bool p0, p1;
-            rows_ok(j - 1, p0, p1);
-            sweep_load_half(Tj - NB, lda, p0, p1, true, A);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[1][q] = __builtin_fma(B[q].y, x1, __builtin_fma(B[q].x, x0, acc[1][q]));
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) colred[(h * 64 + wave * 4 + q) * 65 + lane] = acc[h][q];
-    __syncthreads();
-    {
-        const int cl = tid >> 3, pt = tid & 7;
-        double s = 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += colred[cl * 65 + pt * 8 + u];
-        s += __shfl_down(s, 4, 8);
-        s += __shfl_down(s, 2, 8);
-        s += __shfl_down(s, 1, 8);
-        if (pt == 0) vs[cl] = s;
-    }
-    __syncthreads();
-    if (tid < NB) st_sc1_f64(a.part + ((int64_t)t * a.maxc + c) * NB + tid, vs[tid]);
-}
-
-template <bool BWD, int DIAG>
-__global__ __launch_bounds__(1024) void trsv_chain_kernel(ChainArgs a) {
-    __shared__ double lds[CH_LDS_DOUBLES];
-    __shared__ int s_ticket;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&a.ctl[a.slot], 1);
-    __syncthreads();
-    const int ticket = s_ticket;
-    if (ticket == 0) {
-        sweep_chain_role<BWD, DIAG>(a, lds);
-        return;
-    }
-    const int32_t job = a.jobs[ticket - 1];
-    if (BWD)
-        sweep_helper_bwd(a, lds, job & 0xFFFFF, job >> 20);
-    else
-        sweep_helper_fwd(a, lds, job & 0xFFFFF, job >> 20);
-}
-
 // ---- panel times inverse for ONE 128-column block: L[rows, :] = C[rows, :] W'  (W = inverse of the block's factor) ----
 // The GEMM kernel does this product with a 128 x 128 tile per workgroup: at most n/128 workgroups, one round, 14 us of
 // MFMA per tile behind a staged prologue -- 23 us per launch at n = 5 000, forty times per factorisation.  Here a workgroup
