@@ -702,37 +702,20 @@ __device__ __forceinline__ void ximg_store(const double (&v)[16], double* __rest
     }
 }
 
-// Eight of the 16 values of sub-block g (lanes 16 g + 8 h .. + 7 of `src`) to every lane: DIAG < 3 by 16 read-lanes
-// (scalar operands); DIAG = 3 through LDS -- the caller has stored `src` of all 64 lanes to ub[lane] (sweep_bcast_put),
-// four 16-byte reads of ONE address each are a broadcast; the LDS unit works a wave's requests off in order, so the
-// reads see the store without a wait in between.
-template <int DIAG>
-__device__ __forceinline__ void sweep_bcast_put(double src, int lane, double* __restrict__ ub) {
-    if (DIAG == 3) ub[lane] = src;
-}
-template <int DIAG>
-__device__ __forceinline__ void sweep_bcast8(double src, int g, int h, const double* __restrict__ ub, double (&b)[8]) {
-    if (DIAG == 3) {
-        const double2_t* p = reinterpret_cast<const double2_t*>(ub + 16 * g + 8 * h);
+// Eight of the 16 values of sub-block g (lanes 16 g + 8 h .. + 7 of `src`) to every lane, as scalar operands: 16 read-lanes.
+// (Through LDS instead -- one store of all 64 lanes, four 16-byte reads of one address each -- measured the same time
+// per hop and costs registers: dropped.)
+__device__ __forceinline__ void sweep_bcast8(double src, int g, int h, double (&b)[8]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double2_t v = p[k];
-            b[2 * k] = v.x;
-            b[2 * k + 1] = v.y;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) b[k] = readlane_f64(src, 16 * g + 8 * h + k);
-    }
+    for (int k = 0; k < 8; ++k) b[k] = readlane_f64(src, 16 * g + 8 * h + k);
 }
 // t0 = sum_k x0[k] b[k], t1 = sum_k x1[k] b[k] over the 16 columns of one sub-block (two partial sums each, fixed order);
 // column k of the packed image at X + k * len (+ 64 for the second row of the lane); HAS0 / HAS1: which of the lane's two
 // rows take part (compile time)
 template <int DIAG, bool HAS0, bool HAS1>
 __device__ __forceinline__ void sweep_dot16(const double* __restrict__ X, int len, double src, int g, int lane,
-                                            double* __restrict__ ub, double& t0, double& t1) {
+                                            double& t0, double& t1) {
     double t0a = 0.0, t0b = 0.0, t1a = 0.0, t1b = 0.0;
-    sweep_bcast_put<DIAG>(src, lane, ub);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         double b[8], x0[8], x1[8];
@@ -741,7 +724,7 @@ __device__ __forceinline__ void sweep_dot16(const double* __restrict__ X, int le
             if (HAS0) x0[k] = X[(8 * h + k) * len + lane];
             if (HAS1) x1[k] = X[(8 * h + k) * len + 64 + lane];
         }
-        sweep_bcast8<DIAG>(src, g, h, ub, b);
+        sweep_bcast8(src, g, h, b);
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
             if (HAS0) {
@@ -759,8 +742,7 @@ __device__ __forceinline__ void sweep_dot16(const double* __restrict__ X, int le
 }
 // wave 0: the 128 values of the diagonal step; lane l holds rows l (u0) and 64 + l (u1) on entry (v) and on return (z)
 template <int DIAG>
-__device__ __forceinline__ double2_t sweep_diag_fwd(const double* __restrict__ X, double* __restrict__ ub, int lane,
-                                                    double u0, double u1) {
+__device__ __forceinline__ double2_t sweep_diag_fwd(const double* __restrict__ X, int lane, double u0, double u1) {
     // (inlined, behind a compiler barrier: as a call the callee saves 48 registers to scratch on the chain; without the
     // barrier the image reads drift up into the streaming loop and its registers spill)
     asm volatile("" ::: "memory");
@@ -772,16 +754,16 @@ __device__ __forceinline__ double2_t sweep_diag_fwd(const double* __restrict__ X
         const double src = (J < 4) ? u0 : u1;
         double t0 = 0.0, t1 = 0.0;
         if (J < 4)
-            sweep_dot16<DIAG, true, true>(Xj, len, src, J & 3, lane, ub, t0, t1);
+            sweep_dot16<DIAG, true, true>(Xj, len, src, J & 3, lane, t0, t1);
         else
-            sweep_dot16<DIAG, false, true>(Xj, len, src, J & 3, lane, ub, t0, t1);
+            sweep_dot16<DIAG, false, true>(Xj, len, src, J & 3, lane, t0, t1);
         if (DIAG == 2) {  // plain block substitution: the rows below take z_J, not u_J
             const double zsrc = (J < 4) ? t0 : t1;
             double s0 = 0.0, s1 = 0.0;
             if (J < 4)
-                sweep_dot16<DIAG, true, true>(Xj, len, zsrc, J & 3, lane, ub, s0, s1);
+                sweep_dot16<DIAG, true, true>(Xj, len, zsrc, J & 3, lane, s0, s1);
             else
-                sweep_dot16<DIAG, false, true>(Xj, len, zsrc, J & 3, lane, ub, s0, s1);
+                sweep_dot16<DIAG, false, true>(Xj, len, zsrc, J & 3, lane, s0, s1);
             if (J < 4) t0 = (I0 == J) ? t0 : s0;
             t1 = (4 + I0 == J) ? t1 : s1;
         }
@@ -795,8 +777,7 @@ __device__ __forceinline__ double2_t sweep_diag_fwd(const double* __restrict__ X
     return double2_t{u0, u1};
 }
 template <int DIAG>
-__device__ __forceinline__ double2_t sweep_diag_bwd(const double* __restrict__ X, double* __restrict__ ub, int lane,
-                                                    double u0, double u1) {
+__device__ __forceinline__ double2_t sweep_diag_bwd(const double* __restrict__ X, int lane, double u0, double u1) {
     // (inlined, behind a compiler barrier: as a call the callee saves 48 registers to scratch on the chain; without the
     // barrier the image reads drift up into the streaming loop and its registers spill)
     asm volatile("" ::: "memory");
@@ -808,16 +789,16 @@ __device__ __forceinline__ double2_t sweep_diag_bwd(const double* __restrict__ X
         const double src = (I < 4) ? u0 : u1;
         double t0 = 0.0, t1 = 0.0;
         if (I >= 4)
-            sweep_dot16<DIAG, true, true>(Xi, len, src, I & 3, lane, ub, t0, t1);
+            sweep_dot16<DIAG, true, true>(Xi, len, src, I & 3, lane, t0, t1);
         else
-            sweep_dot16<DIAG, true, false>(Xi, len, src, I & 3, lane, ub, t0, t1);
+            sweep_dot16<DIAG, true, false>(Xi, len, src, I & 3, lane, t0, t1);
         if (DIAG == 2) {
             const double zsrc = (I < 4) ? t0 : t1;
             double s0 = 0.0, s1 = 0.0;
             if (I >= 4)
-                sweep_dot16<DIAG, true, true>(Xi, len, zsrc, I & 3, lane, ub, s0, s1);
+                sweep_dot16<DIAG, true, true>(Xi, len, zsrc, I & 3, lane, s0, s1);
             else
-                sweep_dot16<DIAG, true, false>(Xi, len, zsrc, I & 3, lane, ub, s0, s1);
+                sweep_dot16<DIAG, true, false>(Xi, len, zsrc, I & 3, lane, s0, s1);
             t0 = (J0 == I) ? t0 : s0;
             if (I >= 4) t1 = (4 + J0 == I) ? t1 : s1;
         }
@@ -880,6 +861,13 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     double2_t A[4], B[4];
     if (j1 > j0) sweep_load_half(Lr + (int64_t)j0 * NB * lda, lda, ok0, ok1, vec, A);
     if (DIAG != 0 && owner) ximg_store<false>(xv, ximg, tid);  // (visible to wave 0 after any later barrier)
+    // the right-hand side of this block, fetched NOW: read behind the last barrier it is an L2 round trip on every hop
+    double b0 = 0.0, b1 = 0.0;
+    if (owner) {
+        const int i0 = DIAG != 0 ? lane : (tid & (NB - 1)), i1 = 64 + lane;
+        b0 = i0 < w ? b[row0 + i0] : 0.0;
+        if (DIAG != 0) b1 = i1 < w ? b[row0 + i1] : 0.0;
+    }
     for (int j = j0; j < j1; ++j) {
         const double* Tj = Lr + (int64_t)j * NB * lda;
         sweep_load_half(Tj + 64 * lda, lda, ok0, ok1, vec, B);
@@ -903,29 +891,41 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     red[wave][2 * lane] = a0;
     red[wave][2 * lane + 1] = a1;
     __syncthreads();
-    if (tid < NB) {
-        double sum = red[0][tid];
+    if (DIAG == 0 || !owner) {
+        if (tid < NB) {
+            double sum = red[0][tid];
 #pragma unroll
-        for (int q = 1; q < 16; ++q) sum += red[q][tid];
-        if (!owner) {
-            st_sc1_f64(plan.part + ((int64_t)r * plan.maxc + c) * NB + tid, sum);
-        } else {
-            double far = 0.0;  // the partial sums of this block's other jobs, in column order
-            for (int cc = 0; cc < c; ++cc)
-                far += sweep_poll_one(plan.part + ((int64_t)r * plan.maxc + cc) * NB + tid, fault);
-            vs[tid] = (tid < w) ? (b[row0 + tid] - (far + sum)) : 0.0;
+            for (int q = 1; q < 16; ++q) sum += red[q][tid];
+            if (!owner) {
+                st_sc1_f64(plan.part + ((int64_t)r * plan.maxc + c) * NB + tid, sum);
+            } else {
+                double far = 0.0;  // the partial sums of this block's other jobs, in column order
+                for (int cc = 0; cc < c; ++cc)
+                    far += sweep_poll_one(plan.part + ((int64_t)r * plan.maxc + cc) * NB + tid, fault);
+                vs[tid] = (tid < w) ? (b0 - (far + sum)) : 0.0;
+            }
         }
-    }
-    if (!owner) return;
-    __syncthreads();
-    if (DIAG == 0) {
+        if (!owner) return;
+        __syncthreads();
         const double z0 = sweep_block_product(W0, W1, vs, red, tid, lane, wave);  // z = W v
         if (tid < w) st_sc1_f64(y + row0 + tid, z0);
         return;
     }
     if (wave != 0) return;  // (the image was complete before the first barrier of this workgroup)
-    const double u0 = vs[lane], u1 = vs[64 + lane];
-    const double2_t z = sweep_diag_fwd<DIAG>(ximg, vs, lane, u0, u1);  // (vs is free from here on: the LDS broadcast's 64 slots)
+    // wave 0 alone from here: the sums over the 16 waves for its two rows (the same order as above), no second barrier
+    double s0 = red[0][lane], s1 = red[0][64 + lane];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+        s0 += red[q][lane];
+        s1 += red[q][64 + lane];
+    }
+    double far0 = 0.0, far1 = 0.0;  // the partial sums of this block's other jobs, in column order
+    for (int cc = 0; cc < c; ++cc) {
+        far0 += sweep_poll_one(plan.part + ((int64_t)r * plan.maxc + cc) * NB + lane, fault);
+        far1 += sweep_poll_one(plan.part + ((int64_t)r * plan.maxc + cc) * NB + 64 + lane, fault);
+    }
+    const double u0 = lane < w ? b0 - (far0 + s0) : 0.0, u1 = 64 + lane < w ? b1 - (far1 + s1) : 0.0;
+    const double2_t z = sweep_diag_fwd<DIAG>(ximg, lane, u0, u1);
     if (lane < w) st_sc1_f64(y + row0 + lane, z.x);
     if (64 + lane < w) st_sc1_f64(y + row0 + 64 + lane, z.y);
 }
@@ -994,6 +994,12 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
         sweep_load_half(Lc + (int64_t)jhi * NB, lda, o0, o1, vec, A);
     }
     if (DIAG != 0 && owner) ximg_store<true>(xv, ximg, tid);
+    double y0 = 0.0, y1 = 0.0;  // this block of the right-hand side, fetched now (see the forward kernel)
+    if (owner) {
+        const int i0 = DIAG != 0 ? lane : (tid & (NB - 1)), i1 = 64 + lane;
+        y0 = i0 < w ? y[col0 + i0] : 0.0;
+        if (DIAG != 0) y1 = i1 < w ? y[col0 + i1] : 0.0;
+    }
     for (int j = jhi; j > jlo; --j) {
         bool o0, o1;
         rows_ok(j, o0, o1);
@@ -1036,21 +1042,26 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
         if (tid < NB) st_sc1_f64(plan.part + ((int64_t)rr * plan.maxc + c) * NB + tid, vs[tid]);
         return;
     }
-    if (tid < NB) {
-        double far = 0.0;
-        for (int cc = 0; cc < c; ++cc)
-            far += sweep_poll_one(plan.part + ((int64_t)rr * plan.maxc + cc) * NB + tid, fault);
-        vs[tid] = (tid < w) ? (y[col0 + tid] - (far + vs[tid])) : 0.0;
-    }
-    __syncthreads();
     if (DIAG == 0) {
+        if (tid < NB) {
+            double far = 0.0;
+            for (int cc = 0; cc < c; ++cc)
+                far += sweep_poll_one(plan.part + ((int64_t)rr * plan.maxc + cc) * NB + tid, fault);
+            vs[tid] = (tid < w) ? (y0 - (far + vs[tid])) : 0.0;
+        }
+        __syncthreads();
         const double x0 = sweep_block_product(W0, W1, vs, red, tid, lane, wave);  // x = W' v
         if (tid < w) st_sc1_f64(x + col0 + tid, x0);
         return;
     }
-    if (wave != 0) return;
-    const double u0 = vs[lane], u1 = vs[64 + lane];
-    const double2_t z = sweep_diag_bwd<DIAG>(ximg, vs, lane, u0, u1);
+    if (wave != 0) return;  // wave 0 alone from here, no further barrier
+    double far0 = 0.0, far1 = 0.0;
+    for (int cc = 0; cc < c; ++cc) {
+        far0 += sweep_poll_one(plan.part + ((int64_t)rr * plan.maxc + cc) * NB + lane, fault);
+        far1 += sweep_poll_one(plan.part + ((int64_t)rr * plan.maxc + cc) * NB + 64 + lane, fault);
+    }
+    const double u0 = lane < w ? y0 - (far0 + vs[lane]) : 0.0, u1 = 64 + lane < w ? y1 - (far1 + vs[64 + lane]) : 0.0;
+    const double2_t z = sweep_diag_bwd<DIAG>(ximg, lane, u0, u1);
     if (lane < w) st_sc1_f64(x + col0 + lane, z.x);
     if (64 + lane < w) st_sc1_f64(x + col0 + 64 + lane, z.y);
 }
@@ -1689,7 +1700,6 @@ static int sweep_diag_mode() {
         const char* e = getenv("MADQP_SWEEP_DIAG");
         if (e && strcmp(e, "inv") == 0) return 0;
         if (e && strcmp(e, "sub16") == 0) return 2;
-        if (e && strcmp(e, "nrm16lds") == 0) return 3;  // the normalised images with the LDS broadcast (A/B)
         return 1;
     }();
     return chol_lite() ? mode : 0;
@@ -1722,7 +1732,6 @@ static void launch_sweep(bool bwd, unsigned grid, hipStream_t st, const double* 
     switch (sweep_diag_mode()) {
         case 0: launch_sweep<0>(bwd, grid, st, L, ld, winv, in, out, n, ctl, fault, vec, plan); break;
         case 2: launch_sweep<2>(bwd, grid, st, L, ld, winv, in, out, n, ctl, fault, vec, plan); break;
-        case 3: launch_sweep<3>(bwd, grid, st, L, ld, winv, in, out, n, ctl, fault, vec, plan); break;
         default: launch_sweep<1>(bwd, grid, st, L, ld, winv, in, out, n, ctl, fault, vec, plan); break;
     }
 }
