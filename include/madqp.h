@@ -274,6 +274,14 @@ int32_t madqp_kkt_factorize(madqp_kkt* kkt, int32_t* info_host);
 /* MadNLP.solve!(kkt, w) (src/KKT/normalkkt.jl:182-205): reduce, condense, two triangular
  * sweeps, decondense, finish; w is an UnreducedKKTVector.values, solved in place */
 int32_t madqp_kkt_solve(madqp_kkt* kkt, const madqp_state* st, double* w);
+/* Steps of iterative refinement that madqp_kkt_solve runs ITSELF: w = K^-1 p, then w += K^-1 (p - K w) per step, with
+ * madqp_kkt_mul for the residual.  0 (default): none -- MadNLP.solve!(kkt, w) as src/KKT/normalkkt.jl:182-205 states it.
+ * -1: the AUTO rule -- one step while the factorised matrix has order <= 1024 (MADQP_REFINE_AUTO_MAX), none above.  For
+ * hosts whose loop is not ours: MadIPM's solve_system! (src/linear_solver.jl:19-45) calls solve! once and only looks at the
+ * residual, so the Julia glue asks for -1; the drivers of this repository refine in their own solve_system (option
+ * refine_steps, same rule) and leave this at 0.  Why: DESIGN.md section 4.2 (16 x 16 inverse products against LAPACK's scalar
+ * substitution on small ill-conditioned problems). */
+int32_t madqp_kkt_set_refine(madqp_kkt* kkt, int32_t steps);
 /* MadNLP.mul!(w, kkt, v, alpha, beta) (src/KKT/normalkkt.jl:207-219), with H for a QP */
 int32_t madqp_kkt_mul(madqp_kkt* kkt, const madqp_state* st, double* w, const double* v,
                       double alpha, double beta);

@@ -216,6 +216,12 @@ function _create(F::Symbol, cb::MadNLP.SparseCallback{T, VT}, ind_cons, linear_s
                    ctx.ptr, nx, m, ns, ineq0, dptr(At), lda, ref)
     end
     check(ctx, rc)
+    # MadIPM's solve_system! (src/linear_solver.jl:19-45) calls solve!(kkt, d) once and only looks at the residual: the
+    # refinement step that small ill-conditioned problems need (DESIGN.md section 4.2) therefore runs INSIDE madqp_kkt_solve --
+    # the AUTO rule (-1): one step while the factorised matrix has order <= 1024, none above.  ENV["MADQP_KKT_REFINE"]
+    # overrides ("0" = the plain solve! of src/KKT/normalkkt.jl:182-205).
+    check(ctx, ccall((:madqp_kkt_set_refine, libmadqp), Int32, (Ptr{Cvoid}, Int32), ref[],
+                     parse(Int32, get(ENV, "MADQP_KKT_REFINE", "-1"))))
     order = (F == :augmented || F == :scaled_augmented) ? (cld(nx, 128) * 128 + m) : (F == :normal ? m : nx)
     aug_com = HIPDenseKKTMatrix{T}(ref[], ctx, order, filter(!=(C_NULL), [jac_map, hess_map]))
     ls = linear_solver(aug_com; opt = opt_linear_solver)             # src/KKT/normalkkt.jl:99-101

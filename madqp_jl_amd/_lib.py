@@ -128,6 +128,7 @@ _SIGNATURES = {
     "madqp_kkt_build": [vp, pstate],
     "madqp_kkt_factorize": [vp, pi32],
     "madqp_kkt_solve": [vp, pstate, vp],
+    "madqp_kkt_set_refine": [vp, C.c_int32],
     "madqp_kkt_mul": [vp, pstate, vp, vp, f64, f64],
     "madqp_kkt_mul_solved": [vp, pstate, vp, vp, f64, f64],
     "madqp_kkt_jtprod": [vp, vp, vp],

@@ -334,6 +334,9 @@ class HipBackend:
     def kkt_solve(self, h, st, w):
         self._ck(self.lib.madqp_kkt_solve(h, C.byref(st.cstruct), ptr(w)))
 
+    def kkt_set_refine(self, h, steps):
+        self._ck(self.lib.madqp_kkt_set_refine(h, int(steps)))
+
     def kkt_mul(self, h, st, w, v, alpha, beta, solved=False):
         f = self.lib.madqp_kkt_mul_solved if solved else self.lib.madqp_kkt_mul
         self._ck(f(h, C.byref(st.cstruct), ptr(w), ptr(v), alpha, beta))

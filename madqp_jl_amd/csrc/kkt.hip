@@ -63,6 +63,10 @@ struct madqp_kkt {
     int scaled;             // augmented mode: K2.5 (see the header comment)
     double *sfac, *sb;      // K2.5: scaling factor (n) and a scratch n-vector
     madqp_chol* chol;
+    // refinement steps madqp_kkt_solve runs itself (madqp_kkt_set_refine; 0 = none, the default) and their two work vectors
+    int32_t refine;
+    double *rf_p, *rf_r;
+    int64_t rf_len;
 };
 
 namespace {
@@ -264,6 +268,8 @@ extern "C" int32_t madqp_kkt_destroy(madqp_kkt* k) {
     if (k->b) (void)hipFree(k->b);
     if (k->sfac) (void)hipFree(k->sfac);
     if (k->sb) (void)hipFree(k->sb);
+    if (k->rf_p) (void)hipFree(k->rf_p);
+    if (k->rf_r) (void)hipFree(k->rf_r);
     delete k;
     return MADQP_OK;
 }
@@ -554,11 +560,61 @@ int32_t madqp_kkt_factor_result(madqp_kkt* k, int32_t info) {
     return MADQP_OK;
 }
 
+static int32_t kkt_solve_once(madqp_kkt* k, const madqp_state* st, double* w);
+
+// Steps of iterative refinement INSIDE solve!: w = K^-1 p, then w += K^-1 (p - K w) -- for hosts whose loop is not ours.
+// MadIPM's solve_system! (src/linear_solver.jl:19-45) calls solve!(kkt, d) once and only LOOKS at the residual; the device
+// factorisation multiplies with explicit inverses of 16 x 16 sub-blocks where LAPACK substitutes scalar by scalar, which on
+// small ill-conditioned problems shows in the per-iteration traces and which one step removes.  The
+// Julia glue asks for the AUTO rule (steps = -1: one step while the factorised matrix has order <= 1024, none above -- the
+// rule madqp_jl_amd/options.py applies in the drivers of this repository, which refine in their own solve_system with the
+// residual they form anyway and leave this at 0).  Arithmetic: operation for operation the drivers' (bitwise equal results).
+extern "C" int32_t madqp_kkt_set_refine(madqp_kkt* k, int32_t steps) {
+    if (!k) return MADQP_ERR_ARG;
+    ARG_TRY(k->ctx, steps >= -1 && steps <= 8);
+    if (steps < 0) {
+        const int64_t order = k->mode == KKT_NORMAL ? k->m : k->mode == KKT_AUGMENTED ? k->nx + k->m : k->nx;
+        static const int64_t auto_max = getenv("MADQP_REFINE_AUTO_MAX") ? atoll(getenv("MADQP_REFINE_AUTO_MAX")) : 1024;
+        steps = order <= auto_max ? 1 : 0;
+    }
+    k->refine = steps;
+    return MADQP_OK;
+}
+
 extern "C" int32_t madqp_kkt_solve(madqp_kkt* k, const madqp_state* st, double* w) {
     int32_t r = check_kkt_state(k, st);
     if (r) return r;
+    ARG_TRY(k->ctx, w != nullptr);
+    if (k->refine <= 0) return kkt_solve_once(k, st, w);
     madqp_ctx* ctx = k->ctx;
-    ARG_TRY(ctx, w != nullptr);
+    const int64_t len = st->n + st->m + st->nlb + st->nub;
+    if (len > k->rf_len) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (k->rf_p) (void)hipFree(k->rf_p);
+        if (k->rf_r) (void)hipFree(k->rf_r);
+        k->rf_p = k->rf_r = nullptr;
+        k->rf_len = 0;
+        if (hipMalloc(&k->rf_p, len * sizeof(double)) != hipSuccess || hipMalloc(&k->rf_r, len * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            return madqp_fail(ctx, MADQP_ERR_ALLOC, "madqp_kkt_solve: work vectors of the refinement steps (%lld doubles)", (long long)len);
+        }
+        k->rf_len = len;
+    }
+    if ((r = madqp_copy(ctx, len, w, k->rf_p))) return r;  // p
+    if ((r = kkt_solve_once(k, st, w))) return r;           // w = K^-1 p
+    for (int32_t it = 0; it < k->refine; ++it) {
+        if ((r = madqp_copy(ctx, len, k->rf_p, k->rf_r))) return r;
+        if ((r = madqp_kkt_mul(k, st, k->rf_r, w, -1.0, 1.0))) return r;  // r = p - K w
+        if ((r = kkt_solve_once(k, st, k->rf_r))) return r;
+        if ((r = madqp_axpy(ctx, len, 1.0, k->rf_r, w))) return r;         // w += K^-1 r
+    }
+    k->u_is_A_of = nullptr;  // (u belongs to the last correction, not to w)
+    return MADQP_OK;
+}
+
+static int32_t kkt_solve_once(madqp_kkt* k, const madqp_state* st, double* w) {
+    int32_t r = 0;
+    madqp_ctx* ctx = k->ctx;
     k->u_is_A_of = nullptr;
     double* wx = w;
     double* wy = w + st->n;

@@ -282,7 +282,7 @@ extern "C" int32_t madqp_mpc_create(madqp_kkt* kkt, const madqp_state* st, doubl
     s->reg_delta_p = opt->delta_p;
     s->reg_delta_d = opt->delta_d;
     const char* env = getenv("MADQP_MPC_FUSED");  // 0: the sequential form (A/B tests)
-    s->fused = !(env && env[0] == '0') && opt->step_rule != 2 && opt->refine_steps == 0;
+    s->fused = !(env && env[0] == '0') && opt->step_rule != 2;
     *out = s;
     return MADQP_OK;
 }
@@ -380,6 +380,12 @@ int32_t solve_system_queue(madqp_mpc* s, int slot0) {
     TRY(madqp_kkt_solve(s->kkt, &s->st, s->st.d));
     TRY(madqp_copy(s->ctx, len, s->st.p, s->w1));
     TRY(madqp_kkt_mul_solved(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));
+    for (int32_t it = 0; it < s->opt.refine_steps; ++it) {  // the refinement steps of solve_system, queued like the rest
+        TRY(madqp_kkt_solve(s->kkt, &s->st, s->w1));
+        TRY(madqp_axpy(s->ctx, len, 1.0, s->w1, s->st.d));
+        TRY(madqp_copy(s->ctx, len, s->st.p, s->w1));
+        TRY(madqp_kkt_mul(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));
+    }
     return madqp_q_norm_inf3(s->ctx, len, s->w1, s->st.p, s->st.d, slot0);
 }
 int32_t residual_verdict(madqp_mpc* s, const double* nrm) {  // src/linear_solver.jl:36-43

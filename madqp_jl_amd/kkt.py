@@ -128,6 +128,12 @@ class HIPCondensedKKTSystem:
         self.be.kkt_solve(self._h, self.st, w)
         return w
 
+    def set_refine(self, steps):
+        """Refinement steps ``solve`` runs itself (``madqp_kkt_set_refine``; -1 = the AUTO rule by order).  For hosts whose
+        loop calls ``solve!`` once (MadIPM's ``solve_system!``: what the Julia glue asks for); the drivers of this package
+        refine in their own ``solve_system`` (option ``refine_steps``) and leave this at 0."""
+        self.be.kkt_set_refine(self._h, steps)
+
     def mul(self, w, v, alpha=1.0, beta=0.0):  # MadNLP.mul!, :207-219
         self.be.kkt_mul(self._h, self.st, w, v, alpha, beta)
         return w

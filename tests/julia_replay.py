@@ -18,6 +18,7 @@ the oracle); in particular ``factorize_wrapper!`` is the FIRST plugin call after
 before any ``set_aug_diagonal_reg!``.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -100,6 +101,8 @@ class ReplayKKTSystem:
             ccall(be, "madqp_kkt_create_normal", be.ctx, self.nx, self.m, self.ns, ineq0, ptr(self.At), self.lda,
                   C.byref(h))
         self.handle = h
+        # the glue's AUTO refinement request (ENV["MADQP_KKT_REFINE"], default -1): MadIPM's solve_system! calls solve! once
+        ccall(be, "madqp_kkt_set_refine", h, int(os.environ.get("MADQP_KKT_REFINE", "-1")))
         self.linear_solver = ReplayCholeskySolver(be, h)  # linear_solver(aug_com; opt = opt_linear_solver)
         n, m = self.n, self.m
         self.ind_lb0 = torch.as_tensor(ind_lb, dtype=torch.int64, device=dev).contiguous()

@@ -139,3 +139,37 @@ def test_refinement_step_on_the_edge_of_fp64(hip, driver):
     assert out[0]["status"] == out[1]["status"] == M.SOLVE_SUCCEEDED
     assert out[1]["iter"] <= min(out[0]["iter"], ref["iter"])
     assert abs(out[1]["objective"] - ref["objective"]) <= 1e-7 * max(1.0, abs(ref["objective"]))
+
+
+def test_refinement_inside_solve_is_the_drivers_refinement(hip):
+    """`madqp_kkt_set_refine` (round 5): the refinement step run INSIDE `MadNLP.solve!(kkt, w)` -- what the Julia glue asks for,
+    because MadIPM's own solve_system! (src/linear_solver.jl:19-45) calls solve! once -- is operation for operation the step
+    the drivers of this package run in THEIR solve_system with the residual they form anyway: bitwise the same iterates.
+    Also: with the AUTO rule (-1) a problem of this order refines, and the solver follows the oracle's traces."""
+    from parity import assert_parity
+
+    qp = Q.random_qp(9030, 204, 51, False)  # (78 x the CPU noise floor without refinement in round 4's table)
+    ref = mpc.solve(qp, kkt_system="condensed", regularization=OREG)
+    dq = M.DeviceQP.from_numpy(hip.device, qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
+    out = {}
+    for name, kkt_steps in (("driver", 0), ("inside_solve", 1), ("inside_solve_auto", -1)):
+        s = M.MPCSolver(dq, hip, regularization=REG, driver="python", refine_steps=0)
+        s.initialize()  # (the start point's two solves run before the switch: not refined in any of the three)
+        if name == "driver":
+            s.opt.refine_steps = 1  # (read by solve_system at every call)
+        s.kkt.set_refine(kkt_steps)
+        while s.iteration_head() is None:
+            s.iteration_body()
+        out[name] = dict(iter=s.k, x=s.st.x.cpu().numpy().copy(), trace=[dict(t) for t in s.trace])
+        s.close()
+    assert out["driver"]["iter"] == out["inside_solve"]["iter"] == out["inside_solve_auto"]["iter"]
+    assert np.array_equal(out["driver"]["x"], out["inside_solve"]["x"])
+    assert np.array_equal(out["driver"]["x"], out["inside_solve_auto"]["x"])
+    for a, b in zip(out["driver"]["trace"], out["inside_solve"]["trace"]):
+        assert all(a[k] == b[k] for k in ("alpha_p", "alpha_d", "inf_pr", "inf_du", "mu")), (a, b)
+    # the default library as a whole (AUTO in the driver, start point included) against the oracle, traces and all
+    s = M.MPCSolver(dq, hip, regularization=REG, driver="native")
+    r = s.solve()
+    s.close()
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED
+    assert_parity(r, ref, qp, "soak9030 default", trace=True, regularization=OREG)
