@@ -51,6 +51,11 @@ struct BQ {  // device view of the batch (by value in the kernel arguments); pro
     double *theta, *t, *u, *K, *S, *winv, *tmp, *tn;
     double* sym;      // scratch of the symmetric H products (batch_wg.inc: wg_symv_lower), nullptr: full-matrix passes
     int64_t sym_len;  // doubles per problem
+    // incremental model evaluation (round 5, MADQP_BATCH_INCR): H x of the current iterate and the two products the LAST
+    // solve's residual check formed -- H dx and A' dy, unscaled -- per problem (nx each); nullptr: every iteration
+    // evaluates H x, A x and A' y with passes of their own.  incr_ok[b]: the products belong to the step just taken.
+    double *hx, *raw_h, *raw_at;
+    int32_t* incr_ok;
     double* scal;
     int32_t *status, *iters, *info, *retry_skip;
     int32_t *retry_list, *retry_count;  // the problems of the current x100-retry round, compacted (bq_retry_kernel appends)
@@ -93,6 +98,7 @@ __device__ __forceinline__ madqp_state state_of(const BQ& q, int64_t b) {
 struct Prob {
     const double *H, *A, *qv, *rhs;
     double *theta, *t, *u, *K, *S, *winv, *tmp, *tn, *w1, *scal, *sym;
+    double *hx, *raw_h, *raw_at;
     double c0;
 };
 __device__ __forceinline__ Prob prob_of(const BQ& q, int64_t b) {
@@ -110,6 +116,9 @@ __device__ __forceinline__ Prob prob_of(const BQ& q, int64_t b) {
     p.tmp = q.tmp + b * q.npad;
     p.tn = q.tn ? q.tn + b * q.n : nullptr;
     p.sym = q.sym ? q.sym + b * q.sym_len : nullptr;
+    p.hx = q.hx ? q.hx + b * q.nx : nullptr;
+    p.raw_h = q.hx ? q.raw_h + b * q.nx : nullptr;
+    p.raw_at = q.hx ? q.raw_at + b * q.nx : nullptr;
     p.w1 = q.w1 + b * q.ntot;
     p.scal = q.scal + b * S_COUNT;
     p.c0 = q.c0[b];
@@ -326,6 +335,16 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
         static const bool symv = !(getenv("MADQP_BATCH_SYMV") && atoi(getenv("MADQP_BATCH_SYMV")) == 0);
         q.sym_len = (512 / 64 + 1) * 512;  // SYM_DOUBLES of the widest workgroup program
         if (symv && data->H && nx > 0 && nx <= 512) BALLOC(q.sym, B * q.sym_len);
+    }
+    {   // incremental model evaluation: condensed form without Gondzio corrections (a rejected trial would leave the
+        // products of a direction that was not taken)
+        static const bool incr = !(getenv("MADQP_BATCH_INCR") && atoi(getenv("MADQP_BATCH_INCR")) == 0);
+        if (incr && !normal && opt->max_ncorr == 0 && nx > 0) {
+            BALLOC(q.hx, B * nx, true);
+            BALLOC(q.raw_h, B * nx, true);
+            BALLOC(q.raw_at, B * nx, true);
+        }
+        BALLOC(q.incr_ok, B, true);
     }
     BALLOC(q.scal, B * S_COUNT, true);
     BALLOC(q.status, B, true);
