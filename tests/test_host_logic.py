@@ -253,10 +253,38 @@ def test_augmented_kkt_options():
 
 
 def test_refine_steps_reduce_the_residual():
-    """refine_steps (extension, default 0): d += K^-1 (p - K d) in solve_system, through the fake backend."""
+    """refine_steps (extension): d += K^-1 (p - K d) in solve_system, through the fake backend."""
     qp = Q.synthetic_qp(20250615, 30, 12, "lp")
-    s0, r0 = run(qp)
+    s0, r0 = run(qp, refine_steps=0)
     s1, r1 = run(qp, refine_steps=2)
     assert r0["status"] == r1["status"] == M.SOLVE_SUCCEEDED and abs(r0["iter"] - r1["iter"]) <= 1
     assert abs(r0["objective"] - r1["objective"]) <= 1e-8
     assert s1.last_residual_ratio <= 10 * s0.last_residual_ratio + 1e-14
+
+
+def test_refinement_auto_rule_is_resolved_by_the_order_of_the_factorised_matrix(monkeypatch):
+    """options.py (round 5): refine_steps = None is the AUTO rule -- one step of iterative refinement while the matrix
+    that is factorised (n_x condensed, m normal equations, n_x + m augmented) has order <= 1024 (MADQP_REFINE_AUTO_MAX),
+    none above; an explicit value is taken as it stands."""
+    def make(qp, **opts):
+        dq = M.DeviceQP.from_numpy("cpu", qp.H, qp.q, qp.A, qp.lvar, qp.uvar, qp.lcon, qp.ucon, qp.x0, qp.c0)
+        return M.MPCSolver(dq, FakeBackend(), **opts)
+
+    qp = Q.synthetic_qp(3, 30, 12)
+    lp = Q.synthetic_qp(3, 30, 12, "lp")
+    reg = M.FixedRegularization(1e-8, -1e-8)
+    s = make(qp, regularization=reg)
+    assert s.opt.refine_steps == 1
+    assert make(qp, regularization=reg, refine_steps=0).opt.refine_steps == 0
+    assert make(qp, regularization=reg, refine_steps=2).opt.refine_steps == 2
+    monkeypatch.setenv("MADQP_REFINE_AUTO_MAX", "29")  # condensed: order 30 > 29; normal equations: order 12 <= 29
+    assert make(qp, regularization=reg).opt.refine_steps == 0
+    assert make(lp, kkt_system="normal", regularization=M.FixedRegularization(1e-8, 0.0)).opt.refine_steps == 1
+    monkeypatch.setenv("MADQP_REFINE_AUTO_MAX", "41")  # augmented: order 30 + 12 = 42 > 41
+    assert make(qp, kkt_system="augmented").opt.refine_steps == 0
+    assert make(qp, regularization=reg).opt.refine_steps == 1
+    # and the rule's result is what the oracle's refined run gives: same iteration count, same point
+    monkeypatch.delenv("MADQP_REFINE_AUTO_MAX")
+    r = make(qp, regularization=reg).solve()
+    ref = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8), refine_steps=1)
+    assert r["iter"] == ref["iter"] and np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-9
