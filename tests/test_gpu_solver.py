@@ -341,8 +341,8 @@ def test_fused_iteration_is_bitwise_the_sequential_one_with_two_readbacks(hip):
 
     def run(qp, fused, **kw):
         os.environ["MADQP_MPC_FUSED"] = "1" if fused else "0"
-        kw = dict(kw, refine_steps=0)  # (the fused form is the reference's solve_system!: no refinement steps; at these
-        try:                           # sizes the AUTO rule of options.py would add one)
+        kw = dict(dict(refine_steps=0), **kw)  # (the reference's solve_system! unless a case says otherwise: at these sizes
+        try:                                   # the AUTO rule of options.py would add a refinement step)
             s = M.MPCSolver(to_device(qp, hip), hip, driver="native", **kw)  # the switch is read when the loop object
             r = s.solve()                                                    # is created (initialize)
             r["readbacks"] = hip.mpc_readbacks(s._native)
@@ -363,7 +363,10 @@ def test_fused_iteration_is_bitwise_the_sequential_one_with_two_readbacks(hip):
               dict(regularization=M.FixedRegularization(1e-8, -1e-8), step_rule=M.ConservativeStep(0.99)), True),
              (retry_qp, dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_iter=4), False),
              (Q.synthetic_qp(77, 200, 80), dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=3), True),
-             (Q.synthetic_qp(81, 150, 60, "lp"), dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=2), True))
+             (Q.synthetic_qp(81, 150, 60, "lp"), dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=2), True),
+             # round 5: the refinement steps are queued launches like the rest -- the fused form carries them too
+             (Q.synthetic_qp(79, 140, 60, "lp"), dict(regularization=M.FixedRegularization(1e-8, -1e-8), refine_steps=1), True),
+             (Q.synthetic_qp(77, 200, 80), dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=3, refine_steps=1), True))
     for qp, kw, converges in cases:
         a, b = run(qp, False, **kw), run(qp, True, **kw)
         assert a["status"] == b["status"] and a["iter"] == b["iter"]
@@ -371,6 +374,7 @@ def test_fused_iteration_is_bitwise_the_sequential_one_with_two_readbacks(hip):
         assert a["trace"] == b["trace"] and a["n_factorizations"] == b["n_factorizations"]
         assert np.array_equal(a["solution"], b["solution"]) and a["objective"] == b["objective"]
         if converges and not kw.get("max_ncorr"):  # one read-back for the first termination test, then two per iteration
+            # (with or without refinement steps: they add launches, not read-backs)
             assert b["readbacks"] == 1 + 2 * b["iter"], (b["readbacks"], b["iter"])
         elif converges:  # plus one per tried Gondzio correction beyond the first, at most max_ncorr of them per iteration
             assert 1 + 2 * b["iter"] <= b["readbacks"] <= 1 + (1 + kw["max_ncorr"]) * b["iter"]
