@@ -482,16 +482,24 @@ int32_t madqp_mpc_set_scalars(madqp_mpc* mpc, double mu, double del_w, double de
 /* src/solver.jl:259-283; status_host: 0 continue, 1 SOLVE_SUCCEEDED, 6 MAXIMUM_ITERATIONS_EXCEEDED */
 int32_t madqp_mpc_head(madqp_mpc* mpc, madqp_mpc_info* info_host, int32_t* status_host);
 /* src/solver.jl:288-343; returns MADQP_NUM_NAN for MadNLP.SolveException (src/linear_solver.jl:41-43).
- * Unless Mehrotra's adaptive step rule or refinement steps are selected, the reductions of an iteration are queued in
- * the context's result block and read back three times per iteration, plus twice per tried Gondzio correction
- * (csrc/mpc.hip, body_fused; the
- * iterates are bitwise those of the sequential form, which MADQP_MPC_FUSED=0 selects when the object is created);
- * the residual norms of the next termination test come with the last of the three, so madqp_mpc_head behind a
- * body does not synchronise at all. */
+ * Unless Mehrotra's adaptive step rule is selected, the reductions of an iteration are queued in the context's result
+ * block and fetched twice per iteration, plus once per tried Gondzio correction beyond the first (csrc/mpc.hip,
+ * body_fused; the iterates are bitwise those of the sequential form, which MADQP_MPC_FUSED=0 selects when the object is
+ * created).  Neither fetch leaves the device idle: the decisions the host takes from the first one (residual verdicts,
+ * step lengths, keep or drop the first Gondzio trial) are taken by a one-thread kernel as well, and the update of the
+ * iterates, the model evaluation and the next termination test's norms are queued behind it as kernels that do
+ * nothing when that verdict is "the host takes over" (failed factorisation, failed verdict, a further trial); before
+ * the second fetch the NEXT iteration's diagonal and KKT assembly are queued (K is rebuilt from scratch every
+ * iteration, so a loop that ends there has lost nothing but that assembly).  The host checks every decision of the
+ * device against its own and fails with MADQP_ERR_HIP should they differ.  MADQP_MPC_AHEAD=0 at creation: the round-4
+ * form, nothing queued behind a fetch.  The residual norms of the next termination test come with the second fetch,
+ * so madqp_mpc_head behind a body does not synchronise at all. */
 int32_t madqp_mpc_body(madqp_mpc* mpc, madqp_mpc_info* info_host);
 /* blocking scalar read-backs issued so far by madqp_mpc_head / madqp_mpc_body of the fused form (the reference's loop
  * has about 20 implicit synchronisations per iteration, src/solver.jl:264-343) */
 int32_t madqp_mpc_readbacks(const madqp_mpc* mpc, int64_t* count);
+/* assemblies queued ahead by madqp_mpc_body for the pass after it, and how many of them the next pass took over */
+int32_t madqp_mpc_ahead_stats(const madqp_mpc* mpc, int64_t* queued, int64_t* used);
 
 /* ----------------------------------------- batches of small, equally shaped QPs */
 /* B problems with the same (nx, m) and the same bound / inequality pattern advance in lock step:

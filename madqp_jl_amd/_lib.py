@@ -177,6 +177,7 @@ _SIGNATURES = {
     "madqp_mpc_head": [vp, C.POINTER(CMpcInfo), pi32],
     "madqp_mpc_body": [vp, C.POINTER(CMpcInfo)],
     "madqp_mpc_readbacks": [vp, C.POINTER(C.c_int64)],
+    "madqp_mpc_ahead_stats": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
 }
 _RESTYPE = {"madqp_last_error": C.c_char_p}
 

@@ -386,6 +386,12 @@ class HipBackend:
         self._ck(self.lib.madqp_mpc_readbacks(h, C.byref(n)))
         return n.value
 
+    def mpc_ahead_stats(self, h):
+        """(assemblies madqp_mpc_body queued ahead for the next pass, how many of them that pass took over)."""
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.lib.madqp_mpc_ahead_stats(h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def kkt_matrix(self, h, nx):
         """Torch view (nx x ld, row = column of K) of the library-owned K for inspection."""
         p, ld = C.c_void_p(), C.c_int64()

@@ -97,6 +97,19 @@ int32_t madqp_set_extra_correction_dev(madqp_ctx* ctx, const madqp_state* st, do
 int32_t madqp_q_mpc_trial_alpha(madqp_ctx* ctx, int in, int out, double delta);
 int32_t madqp_q_mpc_mu(madqp_ctx* ctx, int in, int out, int64_t nb, double mu_min, int step_rule, double step_param);
 int32_t madqp_q_mpc_muc(madqp_ctx* ctx, int in, int mu_curr_slot, int out, int64_t nb);
+// body_fused's decisions behind the corrector, on the device (vec_kernels.hip, mpc_decide_kernel): slots of the block
+struct MpcDecide {
+    int info, nrm_pred, nrm_corr, alpha, alpha_gz, trial, out;
+    int gondzio, max_ncorr, check_residual;
+    double tol_linear_solve;
+};
+int32_t madqp_q_mpc_decide(madqp_ctx* ctx, const MpcDecide* a);
+int32_t madqp_copy_if_dev(madqp_ctx* ctx, int64_t len, const double* src, double* dst, const double* flag_dev);
+int32_t madqp_update_iterates_dev(madqp_ctx* ctx, const madqp_state* st, const double* dec_dev);
+int32_t madqp_adjust_boundary_dev(madqp_ctx* ctx, const madqp_state* st, const double* dec_dev, const double* mu_dev);
+// the result block on its way to a pinned host copy, marked by an event: the host waits for the event, not for the stream
+int32_t madqp_results_post(madqp_ctx* ctx, double* h_dst, hipEvent_t ev);
+int32_t madqp_results_wait(madqp_ctx* ctx, const double* h_src, hipEvent_t ev, int count, double* out_host);
 int32_t madqp_q_inf(madqp_ctx* ctx, const madqp_state* st, int slot0);                          // 4 slots
 void madqp_inf_from_block(const double* out4, double* out3);
 int32_t madqp_q_norm_inf3(madqp_ctx* ctx, int64_t len, const double* a, const double* b, const double* c,

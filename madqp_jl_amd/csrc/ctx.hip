@@ -130,6 +130,27 @@ int32_t madqp_read_results(madqp_ctx* ctx, int count, double* out_host) {
     return MADQP_OK;
 }
 
+// The same in two halves: the copy and an event behind it are queued, kernels queued after them run on while the host
+// waits for the event only (mpc.hip).  h_dst: pinned, MADQP_RESULT_SLOTS doubles.
+int32_t madqp_results_post(madqp_ctx* ctx, double* h_dst, hipEvent_t ev) {
+    ARG_TRY(ctx, h_dst && ev);
+    HIP_TRY(ctx, hipMemcpyAsync(h_dst, ctx->d_res, MADQP_RESULT_SLOTS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ev, ctx->stream));
+    return MADQP_OK;
+}
+int32_t madqp_results_wait(madqp_ctx* ctx, const double* h_src, hipEvent_t ev, int count, double* out_host) {
+    ARG_TRY(ctx, count >= 0 && count < MADQP_FAULT_SLOT && out_host && h_src && ev);
+    HIP_TRY(ctx, hipEventSynchronize(ev));
+    memcpy(out_host, h_src, count * sizeof(double));
+    if (h_src[MADQP_FAULT_SLOT] != 0.0) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res + MADQP_FAULT_SLOT, 0, sizeof(double), ctx->stream));
+        return madqp_fail(ctx, MADQP_ERR_HIP,
+                          "triangular sweep hand-off timed out: a producer block never published its solution "
+                          "(device fault word set; results of the last solve are invalid)");
+    }
+    return MADQP_OK;
+}
+
 // Test hook: sets the device fault word as a timed-out sweep would.
 extern "C" int32_t madqp_debug_inject_fault(madqp_ctx* ctx) {
     ARG_TRY(ctx, ctx != nullptr);

@@ -5,23 +5,31 @@
 // overhead of an interpreted driver disappears (it matters for small problems and for batches,
 // where each host thread drives its own context).
 //
-// Blocking read-backs.  The sequential form (body_sequential: every reduction returns its scalar at once) makes about
+// Read-backs.  The sequential form (body_sequential: every reduction returns its scalar at once) makes about
 // ten per iteration, thirteen to sixteen with Gondzio corrections.  The fused form (body_fused; AdaptiveStep /
-// ConservativeStep, no refinement steps) queues the reductions of a phase in the context's result block and reads the
-// block TWICE per iteration, plus once per tried Gondzio correction beyond the first (round 3: three times, plus twice
-// per trial):
-//   (b) after the corrector: factorisation info; residual norms of both solve_system! calls, the predictor's step-length
+// ConservativeStep) queues the reductions of a phase in the context's result block and fetches the block TWICE per
+// iteration, plus once per tried Gondzio correction beyond the first:
+//   (b) behind the corrector: factorisation info; residual norms of both solve_system! calls, the predictor's step-length
 //       minima and the complementarity sums, from which a one-thread kernel (mpc_mu_kernel) has formed sigma, mu and
 //       the step rule's tau ON THE DEVICE -- the corrector's right-hand side and step-length kernels read them there --
 //       then the corrector's step-length minima and |dx|  -> SolveException test BEFORE the iterates move; likewise
 //       a Gondzio trial's mu_c (mpc_muc_kernel) and, for the FIRST trial, its step lengths min(alpha + delta, 1)
-//       (mpc_trial_alpha_kernel): that trial is queued behind the corrector and decided from the same read-back; a
+//       (mpc_trial_alpha_kernel): that trial is queued behind the corrector and decided from the same block; a
 //       further trial costs the one read-back that decides whether it is kept;
-//   (c) after the update: objective sums and the residual norms of the NEXT termination test (madqp_mpc_head then
+//   (c) behind the update: objective sums and the residual norms of the NEXT termination test (madqp_mpc_head then
 //       finds them cached).
-// A read-back is a 28 us round trip, and the launches behind it start from an empty queue -- 3.7 us each from the
-// host against 1.6 us when they are already queued (tools/launch_probe.cpp) -- so each one removed is worth ~0.1 ms at
-// n_x = 5 000.
+// A blocking read-back is a 28 us round trip, and the launches behind it start from an empty queue -- 3.7 us each from
+// the host against 1.6 us when they are already queued (tools/launch_probe.cpp) -- ~0.1 ms at n_x = 5 000 each, plus
+// the driver's way around the loop behind (c).  Round 5: neither fetch leaves the queue empty any more.  The decisions
+// of (b) are ALSO taken by a one-thread kernel (mpc_decide_kernel: the host's arithmetic on the same words), phase
+// (c) is queued behind it as kernels that do nothing unless that kernel said "go on" (update_iterates / adjust_boundary
+// are the two with side effects; the evaluations behind them recompute what they would have anyway), the block is
+// copied to the host behind the decision AND behind (c), and the host waits for the two events: for (b) while (c)
+// runs, and for (c) after it has queued the NEXT iteration's set_aug_diagonal_reg! and build_kkt! (their inputs are
+// final once (c) has run, the regularisation is host arithmetic; K is rebuilt from scratch every pass, so a loop that
+// ends here has lost one assembly).  The host replays every decision from the block and fails loudly if the device's
+// differ; where the device said "the host takes over" (failed factorisation or verdict, a second Gondzio trial) the
+// iterates have not moved and the round-4 flow continues from the same block.  MADQP_MPC_AHEAD=0: the round-4 form.
 // Same kernels, the same arithmetic operation for operation (on the device where the scalar stays there), same order on
 // the stream: the iterates are bitwise those of the sequential form (tests/test_gpu_solver.py).  A failed first factorisation (the x100 retries of src/linear_solver.jl:6-17)
 // sends the rest of that iteration down the sequential form.
@@ -47,6 +55,14 @@ struct madqp_mpc {
     bool head_cached;  // nrm_cached = the residual norms of the current iterate, read with the last body's block (c)
     double nrm_cached[3];
     int64_t n_readbacks;  // blocking scalar read-backs issued by head/body (reported for DESIGN's count)
+    // body_fused, queued ahead of its read-backs (see the head of this file)
+    bool ahead;            // MADQP_MPC_AHEAD != 0
+    double *h_early, *h_final;  // pinned copies of the result block
+    hipEvent_t ev_early, ev_final;
+    bool moved;            // a pass has completed since the scalars were set: f, c are those of the current x
+    bool prebuilt;         // the NEXT iteration's diagonal and K are already queued, with these regularisations:
+    double pre_del_w, pre_del_c;
+    int64_t n_prebuilt, n_prebuilt_used;
 };
 
 madqp_ctx* madqp_kkt_ctx(madqp_kkt* kkt);  // kkt.hip
@@ -283,11 +299,28 @@ extern "C" int32_t madqp_mpc_create(madqp_kkt* kkt, const madqp_state* st, doubl
     s->reg_delta_d = opt->delta_d;
     const char* env = getenv("MADQP_MPC_FUSED");  // 0: the sequential form (A/B tests)
     s->fused = !(env && env[0] == '0') && opt->step_rule != 2;
+    env = getenv("MADQP_MPC_AHEAD");  // 0: body_fused waits for its read-backs with nothing queued behind them (A/B tests)
+    s->ahead = s->fused && !(env && env[0] == '0');
+    if (s->ahead) {
+        hipError_t e = hipHostMalloc((void**)&s->h_early, 2 * MADQP_RESULT_SLOTS * sizeof(double), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_early, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_final, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            madqp_mpc_destroy(s);
+            return madqp_fail(ctx, MADQP_ERR_HIP, "madqp_mpc_create: %s", hipGetErrorString(e));
+        }
+        s->h_final = s->h_early + MADQP_RESULT_SLOTS;
+    }
     *out = s;
     return MADQP_OK;
 }
 
 extern "C" int32_t madqp_mpc_destroy(madqp_mpc* s) {
+    if (s) {
+        if (s->ev_early) (void)hipEventDestroy(s->ev_early);
+        if (s->ev_final) (void)hipEventDestroy(s->ev_final);
+        if (s->h_early) (void)hipHostFree(s->h_early);
+    }
     delete s;
     return MADQP_OK;
 }
@@ -301,6 +334,8 @@ extern "C" int32_t madqp_mpc_set_scalars(madqp_mpc* s, double mu, double del_w, 
     s->obj = obj;
     s->k = k;
     s->head_cached = false;
+    s->prebuilt = false;
+    s->moved = false;
     return MADQP_OK;
 }
 
@@ -400,11 +435,16 @@ inline double min_like_host(double a, double b) { return std::min(a, b); }  // f
 int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
     madqp_ctx* ctx = s->ctx;
     const int64_t nb = s->st.nlb + s->st.nub;
-    double r[16];
     update_regularization(s);  // :288
     // (a) factorisation and predictor
-    TRY(madqp_kkt_set_aug_diagonal_reg(s->kkt, &s->st, s->del_w, s->del_c));
-    TRY(madqp_kkt_build(s->kkt, &s->st));
+    const bool have_k = s->prebuilt && s->pre_del_w == s->del_w && s->pre_del_c == s->del_c;  // queued by the last pass
+    s->prebuilt = false;
+    if (have_k) {
+        s->n_prebuilt_used += 1;
+    } else {
+        TRY(madqp_kkt_set_aug_diagonal_reg(s->kkt, &s->st, s->del_w, s->del_c));
+        TRY(madqp_kkt_build(s->kkt, &s->st));
+    }
     TRY(madqp_q_kkt_factorize(s->kkt, 15));
     s->n_factorizations += 1;
     TRY(madqp_set_predictive_rhs(ctx, &s->st));                                  // :294
@@ -445,20 +485,55 @@ int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
         TRY(madqp_q_alpha_max_dev(ctx, &s->st, 0.0, ctx->d_res + SL_TAU, SL_T_ATAU));  // in case this direction is kept
         TRY(madqp_q_norm_inf3(ctx, s->st.n, s->st.d, nullptr, nullptr, SL_T_DN));      // and is the last one
     }
+    // The decisions of the read-back below, on the device too (SL_DEC ..), and behind them -- ahead of the read-back -- the
+    // update of the iterates and everything up to the next termination test's norms, as kernels that do nothing when
+    // the device's verdict is "the host takes over".  The block travels to the host twice: behind the decision (the host
+    // waits for THAT copy while the update runs) and behind the norms.
+    const int SL_DEC = 100, SL_C = 106;
     double rb[MADQP_RESULT_SLOTS];
-    TRY(madqp_read_results(ctx, gz ? SL_T_DN + 3 : SL_DNORM_B + 3, rb));
+    const int nrb = gz ? SL_T_DN + 3 : SL_DNORM_B + 3;
+    // (Not in the first pass behind the start point: f and c are then the values initialize! left, from BEFORE the start
+    // point moved x -- src/solver.jl:100-146 -- and an evaluation queued ahead would refresh them even where the host
+    // takes over and the reference's loop goes on with the stale ones.)
+    const bool spec = s->ahead && s->moved;
+    if (spec) {
+        MpcDecide dec{15, 0, SL_NRM_B, SL_ALPHA_B, SL_ALPHA_GZ, SL_T_NRM, SL_DEC, gz ? 1 : 0, s->opt.max_ncorr,
+                      s->opt.check_residual ? 1 : 0, s->opt.tol_linear_solve};
+        TRY(madqp_q_mpc_decide(ctx, &dec));
+        TRY(madqp_results_post(ctx, s->h_early, s->ev_early));
+        if (gz) TRY(madqp_copy_if_dev(ctx, len, s->w2, s->st.d, ctx->d_res + SL_DEC + 3));
+        TRY(madqp_update_iterates_dev(ctx, &s->st, ctx->d_res + SL_DEC));                   // :332-335
+        TRY(madqp_q_kkt_eval(s->kkt, &s->st, s->q, s->rhs, SL_C));                          // :338-340
+        TRY(madqp_adjust_boundary_dev(ctx, &s->st, ctx->d_res + SL_DEC, ctx->d_res + SL_MU)); // :342
+        TRY(madqp_kkt_jtprod(s->kkt, s->st.jacl, s->st.y));                                 // :259-283 of the next pass
+        TRY(madqp_q_inf(ctx, &s->st, SL_C + 2));
+        TRY(madqp_results_post(ctx, s->h_final, s->ev_final));
+        TRY(madqp_results_wait(ctx, s->h_early, s->ev_early, SL_DEC + 4, rb));
+    } else {
+        TRY(madqp_read_results(ctx, nrb, rb));
+    }
     s->n_readbacks += 1;
+    const bool went = spec && rb[SL_DEC] != 0.0;  // the device has gone on: the host's decisions must be the same
+    auto differ = [&]() {
+        return madqp_fail(ctx, MADQP_ERR_HIP, "body_fused: the device's decisions behind the corrector are not the host's");
+    };
     s->last_info = (int32_t)rb[15];
     TRY(madqp_kkt_factor_result(s->kkt, s->last_info));
     if (s->last_info != 0) {  // src/linear_solver.jl:6-17: what was queued behind the failed factorisation is void
+        if (went) return differ();
         s->del_w *= 100.0;
         s->del_c *= 100.0;
         TRY(factorize_regularized_system(s, 1));
         return body_after_factorization(s, info_host);
     }
-    TRY(residual_verdict(s, rb));             // the predictor's solve
-    s->mu = rb[SL_MU];
-    TRY(residual_verdict(s, rb + SL_NRM_B));  // the corrector's
+    {
+        int32_t v = residual_verdict(s, rb);  // the predictor's solve
+        if (!v) {
+            s->mu = rb[SL_MU];
+            v = residual_verdict(s, rb + SL_NRM_B);  // the corrector's
+        }
+        if (v) return went ? differ() : v;
+    }
     s->alpha_p = min_like_host(rb[SL_ALPHA_B + 0], rb[SL_ALPHA_B + 2]);
     s->alpha_d = min_like_host(rb[SL_ALPHA_B + 4], rb[SL_ALPHA_B + 6]);
     s->dnorm = rb[SL_DNORM_B];
@@ -469,6 +544,7 @@ int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
         double tr[32];
         for (int c = 0; c < s->opt.max_ncorr; ++c) {
             if (c > 0) {
+                if (went) return differ();
                 const double ta_p = std::min(g_ap + gz_delta, 1.0), ta_d = std::min(g_ad + gz_delta, 1.0);
                 TRY(madqp_q_compl(ctx, &s->st, 1, ta_p, ta_d, nullptr, 0));
                 TRY(madqp_q_mpc_muc(ctx, 0, SL_MUCURR, SL_MUC, nb));
@@ -483,12 +559,20 @@ int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
                 s->n_readbacks += 1;
                 tb = tr;
             }
-            TRY(residual_verdict(s, tb));
+            {
+                const int32_t v = residual_verdict(s, tb);
+                if (v) return went ? differ() : v;
+            }
             const double ha_p = min_like_host(tb[3], tb[5]), ha_d = min_like_host(tb[7], tb[9]);
             if (ha_p < 1.005 * g_ap || ha_d < 1.005 * g_ad) {
-                TRY(madqp_copy(ctx, len, s->w2, s->st.d));  // the direction before it, whose step is already known
+                if (went) {
+                    if (rb[SL_DEC + 3] == 0.0) return differ();  // (the device has put the direction back itself)
+                } else {
+                    TRY(madqp_copy(ctx, len, s->w2, s->st.d));  // the direction before it, whose step is already known
+                }
                 break;
             }
+            if (went && c == 0 && rb[SL_DEC + 3] != 0.0) return differ();
             g_ap = ha_p;
             g_ad = ha_d;
             s->alpha_p = min_like_host(tb[11], tb[13]);
@@ -496,15 +580,41 @@ int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
             s->dnorm = tb[19];
         }
     }
+    if (went && (rb[SL_DEC + 1] != s->alpha_p || rb[SL_DEC + 2] != s->alpha_d)) return differ();
     // (c) update, objective, and the residuals the next termination test needs
-    TRY(madqp_update_iterates(ctx, &s->st, s->alpha_p, s->alpha_d));  // :332-335
-    TRY(madqp_q_kkt_eval(s->kkt, &s->st, s->q, s->rhs, 0));           // :338-340
-    TRY(madqp_adjust_boundary(ctx, &s->st, s->mu));                   // :342
+    if (!went) {
+        TRY(madqp_update_iterates(ctx, &s->st, s->alpha_p, s->alpha_d));  // :332-335
+        TRY(madqp_q_kkt_eval(s->kkt, &s->st, s->q, s->rhs, SL_C));        // :338-340
+        TRY(madqp_adjust_boundary(ctx, &s->st, s->mu));                   // :342
+        TRY(madqp_kkt_jtprod(s->kkt, s->st.jacl, s->st.y));               // :259-283 of the next pass
+        TRY(madqp_q_inf(ctx, &s->st, SL_C + 2));
+        if (s->ahead) TRY(madqp_results_post(ctx, s->h_final, s->ev_final));
+    }
+    if (s->ahead) {
+        // Queue the NEXT iteration's diagonal and assembly before waiting for the norms: the device does not run dry
+        // across the read-back and the driver's way around the loop (K is rebuilt from scratch every iteration; should
+        // the loop end here, a K nobody factors is all that happened)
+        // (not when this pass is the last one allowed, nor when the iterate it started from was already within 100 x the
+        // tolerance: the loop then usually ends behind this pass or the next, and the assembly would be for nobody)
+        const double worst = std::max(s->inf_pr, std::max(s->inf_du, s->inf_compl));
+        if (s->k + 1 < s->opt.max_iter && !(worst <= 100.0 * s->opt.tol)) {
+            madqp_mpc nx = *s;  // the regularisation of the next pass, from a copy of the scalars
+            update_regularization(&nx);
+            TRY(madqp_kkt_set_aug_diagonal_reg(s->kkt, &s->st, nx.del_w, nx.del_c));
+            TRY(madqp_kkt_build(s->kkt, &s->st));
+            s->prebuilt = true;
+            s->pre_del_w = nx.del_w;
+            s->pre_del_c = nx.del_c;
+            s->n_prebuilt += 1;
+        }
+        TRY(madqp_results_wait(ctx, s->h_final, s->ev_final, SL_C + 6, rb));
+    } else {
+        TRY(madqp_read_results(ctx, SL_C + 6, rb));
+    }
+    s->moved = true;
     s->k += 1;
-    TRY(madqp_kkt_jtprod(s->kkt, s->st.jacl, s->st.y));               // :259-283 of the next pass
-    TRY(madqp_q_inf(ctx, &s->st, 2));
-    TRY(madqp_read_results(ctx, 6, r));
     s->n_readbacks += 1;
+    const double* r = rb + SL_C;
     s->obj = s->c0 + r[0] + 0.5 * r[1];
     madqp_inf_from_block(r + 2, s->nrm_cached);
     s->head_cached = true;
@@ -518,11 +628,21 @@ int32_t body_fused(madqp_mpc* s, madqp_mpc_info* info_host) {
 extern "C" int32_t madqp_mpc_body(madqp_mpc* s, madqp_mpc_info* info_host) {
     if (!s) return MADQP_ERR_ARG;
     s->head_cached = false;
-    return s->fused ? body_fused(s, info_host) : body_sequential(s, info_host);
+    if (!s->fused) return body_sequential(s, info_host);
+    const int32_t r = body_fused(s, info_host);
+    if (r) s->prebuilt = false;
+    return r;
 }
 
 extern "C" int32_t madqp_mpc_readbacks(const madqp_mpc* s, int64_t* count) {
     if (!s || !count) return MADQP_ERR_ARG;
     *count = s->n_readbacks;
+    return MADQP_OK;
+}
+
+extern "C" int32_t madqp_mpc_ahead_stats(const madqp_mpc* s, int64_t* queued, int64_t* used) {
+    if (!s || !queued || !used) return MADQP_ERR_ARG;
+    *queued = s->n_prebuilt;
+    *used = s->n_prebuilt_used;
     return MADQP_OK;
 }

@@ -187,6 +187,118 @@ int32_t madqp_q_mpc_muc(madqp_ctx* ctx, int in, int mu_curr_slot, int out, int64
     return MADQP_OK;
 }
 
+// The decisions body_fused takes from its read-back behind the corrector, taken on the device as well so that the
+// update of the iterates can be queued behind the corrector WITHOUT waiting for that read-back (mpc.hip): the residual
+// verdicts of both solve_system! calls (src/linear_solver.jl:36-43), the step lengths min(lower, upper) and, with
+// Gondzio corrections, whether the first trial is kept (src/solver.jl:231) -- the host's arithmetic, operation for
+// operation, on the same words.  res[out] = 1: the iteration goes on as queued (0: the host takes over: failed
+// factorisation, failed verdict, or a further trial to run); res[out+1], [out+2] = alpha_p, alpha_d;
+// res[out+3] = 1: the trial's direction is dropped, the one saved before it comes back.
+__global__ void mpc_decide_kernel(double* __restrict__ res, MpcDecide a) {
+    if (threadIdx.x || blockIdx.x) return;
+    auto bad = [&](const double* nrm) {
+        const double den = (1.0 < nrm[1]) ? nrm[1] : 1.0;  // std::max(1.0, nrm[1])
+        const double ratio = nrm[0] / den;
+        return (ratio != ratio) || (a.check_residual && ratio > a.tol_linear_solve);
+    };
+    auto mn = [](double x, double y) { return (y < x) ? y : x; };  // std::min(x, y)
+    bool go = res[a.info] == 0.0 && !bad(res + a.nrm_pred) && !bad(res + a.nrm_corr);
+    double ap = mn(res[a.alpha + 0], res[a.alpha + 2]), ad = mn(res[a.alpha + 4], res[a.alpha + 6]);
+    bool restore = false;
+    if (a.gondzio) {
+        const double g_ap = mn(res[a.alpha_gz + 0], res[a.alpha_gz + 2]), g_ad = mn(res[a.alpha_gz + 4], res[a.alpha_gz + 6]);
+        const double* tb = res + a.trial;  // norms [0..2], steps at Gondzio's tau [3..10], steps at the rule's tau [11..18]
+        go = go && !bad(tb);
+        const double ha_p = mn(tb[3], tb[5]), ha_d = mn(tb[7], tb[9]);
+        if (ha_p < 1.005 * g_ap || ha_d < 1.005 * g_ad) {
+            restore = go;
+        } else {
+            ap = mn(tb[11], tb[13]);
+            ad = mn(tb[15], tb[17]);
+            if (a.max_ncorr > 1) go = false;  // the next trial is the host's to queue
+        }
+    }
+    res[a.out] = go ? 1.0 : 0.0;
+    res[a.out + 1] = ap;
+    res[a.out + 2] = ad;
+    res[a.out + 3] = restore ? 1.0 : 0.0;
+}
+int32_t madqp_q_mpc_decide(madqp_ctx* ctx, const MpcDecide* a) {
+    if (!ctx || !a) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, a->out >= 0 && a->out + 4 <= MADQP_FAULT_SLOT);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    hipLaunchKernelGGL(mpc_decide_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_res, *a);
+    LAUNCH_CHECK(ctx);
+    return MADQP_OK;
+}
+// dst = src where *flag != 0 (the dropped Gondzio trial's direction goes back, src/solver.jl:232)
+__global__ __launch_bounds__(TPB) void copy_if_kernel(int64_t len, const double* __restrict__ src, double* __restrict__ dst,
+                                                      const double* __restrict__ flag) {
+    if (*flag == 0.0) return;
+    GRID_STRIDE(i, len) dst[i] = src[i];
+}
+int32_t madqp_copy_if_dev(madqp_ctx* ctx, int64_t len, const double* src, double* dst, const double* flag_dev) {
+    if (!ctx) return MADQP_ERR_ARG;
+    ARG_TRY(ctx, len >= 0 && (len == 0 || (src && dst)) && flag_dev);
+    if (len == 0) return MADQP_OK;
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    LAUNCH(copy_if_kernel, len, len, src, dst, flag_dev);
+    return MADQP_OK;
+}
+// update_iterates / adjust_boundary with their scalars in the result block, and nothing done when dec[0] == 0
+__global__ __launch_bounds__(TPB) void update_iterates_dev_kernel(madqp_state s, const double* __restrict__ dec) {
+    if (dec[0] == 0.0) return;
+    const double ap = dec[1], ad = dec[2];
+    const double* dx = s.d;
+    const double* dy = s.d + s.n;
+    const double* dzl = dy + s.m;
+    const double* dzu = dzl + s.nlb;
+    int64_t L = s.n;
+    if (s.m > L) L = s.m;
+    if (s.nlb > L) L = s.nlb;
+    if (s.nub > L) L = s.nub;
+    GRID_STRIDE(i, L) {
+        if (i < s.n) s.x[i] += ap * dx[i];
+        if (i < s.m) s.y[i] += ad * dy[i];
+        if (i < s.nlb) s.zl[s.ind_lb[i]] += ad * dzl[i];
+        if (i < s.nub) s.zu[s.ind_ub[i]] += ad * dzu[i];
+    }
+}
+__global__ __launch_bounds__(TPB) void adjust_boundary_dev_kernel(madqp_state s, const double* __restrict__ dec,
+                                                                  const double* __restrict__ mu_dev, double eps, double c2) {
+    if (dec[0] == 0.0) return;
+    const double c1 = eps * *mu_dev;
+    const int64_t L = s.nlb > s.nub ? s.nlb : s.nub;
+    GRID_STRIDE(i, L) {
+        if (i < s.nlb) {
+            const int64_t j = s.ind_lb[i];
+            const double x = s.x[j], l = s.xl[j];
+            if (x - l < c1) s.xl[j] = l - c2 * fmax(1.0, fabs(x));
+        }
+        if (i < s.nub) {
+            const int64_t j = s.ind_ub[i];
+            const double x = s.x[j], u = s.xu[j];
+            if (u - x < c1) s.xu[j] = u + c2 * fmax(1.0, fabs(x));
+        }
+    }
+}
+int32_t madqp_update_iterates_dev(madqp_ctx* ctx, const madqp_state* st, const double* dec_dev) {
+    CHECK_STATE();
+    ARG_TRY(ctx, dec_dev != nullptr);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    LAUNCH(update_iterates_dev_kernel, max4(st->n, st->m, st->nlb, st->nub), *st, dec_dev);
+    return MADQP_OK;
+}
+int32_t madqp_adjust_boundary_dev(madqp_ctx* ctx, const madqp_state* st, const double* dec_dev, const double* mu_dev) {
+    CHECK_STATE();
+    ARG_TRY(ctx, dec_dev && mu_dev);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    if (std::max(st->nlb, st->nub) > 0)
+        LAUNCH(adjust_boundary_dev_kernel, std::max(st->nlb, st->nub), *st, dec_dev, mu_dev, 2.220446049250313e-16,
+               1.8189894035458565e-12);
+    return MADQP_OK;
+}
+
 // Queued forms (madqp_q_*): the reduction lands in the device result block at slot0 and stays there; the caller
 // reads several of them back with ONE madqp_read_results (mpc.hip).  The extern "C" entry points below are the
 // queued form at slot 0 followed by the read-back.

@@ -346,6 +346,7 @@ def test_fused_iteration_is_bitwise_the_sequential_one_with_two_readbacks(hip):
             s = M.MPCSolver(to_device(qp, hip), hip, driver="native", **kw)  # the switch is read when the loop object
             r = s.solve()                                                    # is created (initialize)
             r["readbacks"] = hip.mpc_readbacks(s._native)
+            r["ahead"] = hip.mpc_ahead_stats(s._native)
             s.close()
         finally:
             os.environ.pop("MADQP_MPC_FUSED", None)
@@ -367,12 +368,27 @@ def test_fused_iteration_is_bitwise_the_sequential_one_with_two_readbacks(hip):
              # round 5: the refinement steps are queued launches like the rest -- the fused form carries them too
              (Q.synthetic_qp(79, 140, 60, "lp"), dict(regularization=M.FixedRegularization(1e-8, -1e-8), refine_steps=1), True),
              (Q.synthetic_qp(77, 200, 80), dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=3, refine_steps=1), True))
+    def run_waiting(qp, **kw):  # the fused form of round 4: nothing queued behind a read-back
+        os.environ["MADQP_MPC_AHEAD"] = "0"
+        try:
+            return run(qp, True, **kw)
+        finally:
+            os.environ.pop("MADQP_MPC_AHEAD", None)
+
     for qp, kw, converges in cases:
-        a, b = run(qp, False, **kw), run(qp, True, **kw)
-        assert a["status"] == b["status"] and a["iter"] == b["iter"]
+        a, b, w = run(qp, False, **kw), run(qp, True, **kw), run_waiting(qp, **kw)
+        assert a["status"] == b["status"] == w["status"] and a["iter"] == b["iter"] == w["iter"]
         assert (a["status"] == M.SOLVE_SUCCEEDED) == converges
-        assert a["trace"] == b["trace"] and a["n_factorizations"] == b["n_factorizations"]
+        assert a["trace"] == b["trace"] == w["trace"] and a["n_factorizations"] == b["n_factorizations"] == w["n_factorizations"]
         assert np.array_equal(a["solution"], b["solution"]) and a["objective"] == b["objective"]
+        assert np.array_equal(a["solution"], w["solution"]) and a["objective"] == w["objective"]
+        # queued ahead (round 5): a pass finds its K assembled by the pass before it -- all but the first, and the last ones,
+        # which start within 100 x the tolerance and queue nothing; at most one assembly is for nobody
+        assert w["ahead"] == (0, 0)
+        queued, used = b["ahead"]
+        assert used <= queued <= b["iter"] and queued - used <= 1
+        if converges and b["iter"] >= 6:
+            assert used >= 2, (b["ahead"], b["iter"])
         if converges and not kw.get("max_ncorr"):  # one read-back for the first termination test, then two per iteration
             # (with or without refinement steps: they add launches, not read-backs)
             assert b["readbacks"] == 1 + 2 * b["iter"], (b["readbacks"], b["iter"])
