@@ -816,20 +816,27 @@ __global__ __launch_bounds__(256) void negate_kernel(double* __restrict__ v, int
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) v[i] = -v[i];
 }
 
-template <int DIAG>
+// REV (DIAG = 1 only): the same sweep on U = L' from the far end -- the backward substitution x = L^-T y as sums over the
+// ROWS of U's blocks: block r of the chain is block nblk-1-r of the matrix, its sources lie to the right of the diagonal,
+// the diagonal step is the backward one on the block's second image.  The mid-size factorisation leaves U in a buffer of
+// its own (lower_to_upper_kernel); two accumulators per thread where the transposed product on L (trsv_bwd_sweep_kernel)
+// needs sixteen and a column reduction through LDS per block: 3.3 us per hop instead of 4.3.  out: optional second copy
+// of the solution (plain stores; the polled copy y may then be scratch memory).
+template <int DIAG, bool REV = false>
 __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __restrict__ L, int64_t lda,
                                                               const double* __restrict__ winv,
                                                               const double* __restrict__ b,
                                                               double* __restrict__ y, int64_t n,
                                                               int32_t* __restrict__ ctl, double* __restrict__ fault,
-                                                              int vec, SweepPlan plan) {
+                                                              int vec, SweepPlan plan, double* __restrict__ out) {
+    static_assert(!REV || DIAG == 1, "the sweep on U runs the substituting diagonal step");
     __shared__ double xs[2][NB];
     __shared__ double red[16][NB];
     __shared__ double vs[NB];
     __shared__ double ximg[DIAG ? XIMG_DOUBLES : 1];
     __shared__ int s_r;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_r = atomicAdd(&ctl[1], 1);
+    if (tid == 0) s_r = atomicAdd(&ctl[REV ? 2 : 1], 1);
     __syncthreads();
     int r = s_r, c = 0, j0 = 0, j1 = r;
     if (plan.jobs) {
@@ -840,6 +847,9 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
         j1 = (j0 + plan.chunk < r) ? j0 + plan.chunk : r;
     }
     const bool owner = (j1 == r);
+    const int rl = r;  // the block's place in the chain (partial sums are filed under it)
+    const int nblk = (int)((n + NB - 1) / NB);
+    if (REV) r = nblk - 1 - r;  // from here on r is the block of the matrix
     const int64_t row0 = (int64_t)r * NB;
     const int w = (int)((n - row0 < NB) ? (n - row0) : NB);
     const bool ok0 = row0 + 2 * lane < n, ok1 = row0 + 2 * lane + 1 < n;
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     double2_t W0[4], W1[4];
     double xv[16];
     if (owner) {
-        const double* Wcm = winv + (int64_t)r * WBLK;
+        const double* Wcm = winv + (int64_t)r * WBLK + (REV ? NB * NB : 0);
         if (DIAG == 0) {
             sweep_load_half(Wcm + 2 * lane + (int64_t)(wave * 4) * NB, NB, true, true, true, W0);
             sweep_load_half(Wcm + 2 * lane + (int64_t)(64 + wave * 4) * NB, NB, true, true, true, W1);
@@ -858,9 +868,10 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     }
     double a0 = 0.0, a1 = 0.0;
     const double* Lr = L + row0 + 2 * lane + (int64_t)(wave * 4) * lda;  // this thread's corner of tile (r, 0)
+    auto col = [&](int j) { return (int64_t)(REV ? nblk - 1 - j : j) * NB * lda; };  // tile column of source j of the chain
     double2_t A[4], B[4];
-    if (j1 > j0) sweep_load_half(Lr + (int64_t)j0 * NB * lda, lda, ok0, ok1, vec, A);
-    if (DIAG != 0 && owner) ximg_store<false>(xv, ximg, tid);  // (visible to wave 0 after any later barrier)
+    if (j1 > j0) sweep_load_half(Lr + col(j0), lda, ok0, ok1, vec, A);
+    if (DIAG != 0 && owner) ximg_store<REV>(xv, ximg, tid);  // (visible to wave 0 after any later barrier)
     // the right-hand side of this block, fetched NOW: read behind the last barrier it is an L2 round trip on every hop
     double b0 = 0.0, b1 = 0.0;
     if (owner) {
@@ -869,9 +880,9 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
         if (DIAG != 0) b1 = i1 < w ? b[row0 + i1] : 0.0;
     }
     for (int j = j0; j < j1; ++j) {
-        const double* Tj = Lr + (int64_t)j * NB * lda;
+        const double* Tj = Lr + col(j);
         sweep_load_half(Tj + 64 * lda, lda, ok0, ok1, vec, B);
-        if (wave == 0) sweep_poll_block(y, j, n, xs[j & 1], fault, lane);
+        if (wave == 0) sweep_poll_block(y, REV ? nblk - 1 - j : j, n, xs[j & 1], fault, lane);
         __syncthreads();
         const double* xj = xs[j & 1];
 #pragma unroll
@@ -880,7 +891,7 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
             a0 = __builtin_fma(A[q].x, xv, a0);
             a1 = __builtin_fma(A[q].y, xv, a1);
         }
-        if (j + 1 < j1) sweep_load_half(Tj + (int64_t)NB * lda, lda, ok0, ok1, vec, A);
+        if (j + 1 < j1) sweep_load_half(Lr + col(j + 1), lda, ok0, ok1, vec, A);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double xv = xj[64 + wave * 4 + q];
@@ -897,11 +908,11 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
 #pragma unroll
             for (int q = 1; q < 16; ++q) sum += red[q][tid];
             if (!owner) {
-                st_sc1_f64(plan.part + ((int64_t)r * plan.maxc + c) * NB + tid, sum);
+                st_sc1_f64(plan.part + ((int64_t)rl * plan.maxc + c) * NB + tid, sum);
             } else {
                 double far = 0.0;  // the partial sums of this block's other jobs, in column order
                 for (int cc = 0; cc < c; ++cc)
-                    far += sweep_poll_one(plan.part + ((int64_t)r * plan.maxc + cc) * NB + tid, fault);
+                    far += sweep_poll_one(plan.part + ((int64_t)rl * plan.maxc + cc) * NB + tid, fault);
                 vs[tid] = (tid < w) ? (b0 - (far + sum)) : 0.0;
             }
         }
@@ -909,6 +920,7 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
         __syncthreads();
         const double z0 = sweep_block_product(W0, W1, vs, red, tid, lane, wave);  // z = W v
         if (tid < w) st_sc1_f64(y + row0 + tid, z0);
+        if (out && tid < w) out[row0 + tid] = z0;
         return;
     }
     if (wave != 0) return;  // (the image was complete before the first barrier of this workgroup)
@@ -921,13 +933,44 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
     }
     double far0 = 0.0, far1 = 0.0;  // the partial sums of this block's other jobs, in column order
     for (int cc = 0; cc < c; ++cc) {
-        far0 += sweep_poll_one(plan.part + ((int64_t)r * plan.maxc + cc) * NB + lane, fault);
-        far1 += sweep_poll_one(plan.part + ((int64_t)r * plan.maxc + cc) * NB + 64 + lane, fault);
+        far0 += sweep_poll_one(plan.part + ((int64_t)rl * plan.maxc + cc) * NB + lane, fault);
+        far1 += sweep_poll_one(plan.part + ((int64_t)rl * plan.maxc + cc) * NB + 64 + lane, fault);
     }
     const double u0 = lane < w ? b0 - (far0 + s0) : 0.0, u1 = 64 + lane < w ? b1 - (far1 + s1) : 0.0;
-    const double2_t z = sweep_diag_fwd<DIAG>(ximg, lane, u0, u1);
+    const double2_t z = REV ? sweep_diag_bwd<DIAG>(ximg, lane, u0, u1) : sweep_diag_fwd<DIAG>(ximg, lane, u0, u1);
     if (lane < w) st_sc1_f64(y + row0 + lane, z.x);
     if (64 + lane < w) st_sc1_f64(y + row0 + 64 + lane, z.y);
+    if (out) {
+        if (lane < w) out[row0 + lane] = z.x;
+        if (64 + lane < w) out[row0 + 64 + lane] = z.y;
+    }
+}
+
+// U = L' for the tiles strictly below the diagonal blocks (64 x 64 pieces through LDS; rows of L at or beyond n give zeros:
+// the sweep on U multiplies those columns with zeros and must not meet a NaN there)
+__global__ __launch_bounds__(256) void lower_to_upper_kernel(const double* __restrict__ A, int64_t lda, int64_t n,
+                                                            double* __restrict__ U, int64_t ldu) {
+    const int i = blockIdx.x, j = blockIdx.y;  // 64-blocks: source rows i, source columns j
+    if ((i >> 1) <= (j >> 1)) return;
+    __shared__ double tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r = (int64_t)i * 64 + tx;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = ty + 4 * q;
+        tile[c][tx] = r < n ? A[r + ((int64_t)j * 64 + c) * lda] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int rr = ty + 4 * q;  // source row inside the piece = destination column
+        U[(int64_t)j * 64 + tx + ((int64_t)i * 64 + rr) * ldu] = tile[tx][rr];
+    }
+}
+// the scratch vectors of a solve <- sentinel, the sweeps' ticket counters <- 0: one launch per solve instead of three fills
+__global__ __launch_bounds__(256) void sweep_prep_kernel(unsigned long long* __restrict__ v, int64_t len, int32_t* __restrict__ ctl) {
+    if (blockIdx.x == 0 && threadIdx.x < 3) ctl[1 + threadIdx.x] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) v[i] = SWEEP_SENTINEL;
 }
 
 template <int DIAG>
@@ -1595,6 +1638,12 @@ extern "C" int32_t madqp_chol_create(madqp_ctx* ctx, int64_t n, madqp_chol** out
         e = hipMalloc(&s->d_jobs, jobs.size() * sizeof(int32_t));
         if (e == hipSuccess) e = hipMemcpy(s->d_jobs, jobs.data(), jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     }
+    s->upper = nullptr;
+    s->upper_ld = 0;
+    s->upper_ok = false;
+    s->utmp = nullptr;
+    s->utmp_len = 2 * nblk * NB + 2 * nblk * (int64_t)s->sweep_maxc * NB;
+    if (e == hipSuccess && nblk > 1 && nblk <= 160) e = hipMalloc(&s->utmp, s->utmp_len * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&s->d_info, 8 * sizeof(int32_t));  // [0] info, [1..2] sweep tickets
     if (e != hipSuccess) {
         madqp_chol_destroy(s);
@@ -1624,6 +1673,8 @@ extern "C" int32_t madqp_chol_destroy(madqp_chol* s) {
     if (s->d_jobs) (void)hipFree(s->d_jobs);
     if (s->d_info) (void)hipFree(s->d_info);
     if (s->d_mid_plan) (void)hipFree(s->d_mid_plan);
+    if (s->upper) (void)hipFree(s->upper);
+    if (s->utmp) (void)hipFree(s->utmp);
     delete[] s->mid_units;
     delete s;
     return MADQP_OK;
@@ -1725,7 +1776,8 @@ static void launch_sweep(bool bwd, unsigned grid, hipStream_t st, const double* 
     if (bwd)
         hipLaunchKernelGGL(trsv_bwd_sweep_kernel<DIAG>, dim3(grid), dim3(1024), 0, st, L, ld, winv, in, out, n, ctl, fault, vec, plan);
     else
-        hipLaunchKernelGGL(trsv_fwd_sweep_kernel<DIAG>, dim3(grid), dim3(1024), 0, st, L, ld, winv, in, out, n, ctl, fault, vec, plan);
+        hipLaunchKernelGGL(trsv_fwd_sweep_kernel<DIAG>, dim3(grid), dim3(1024), 0, st, L, ld, winv, in, out, n, ctl, fault, vec, plan,
+                           (double*)nullptr);
 }
 static void launch_sweep(bool bwd, unsigned grid, hipStream_t st, const double* L, int64_t ld, const double* winv, const double* in,
                          double* out, int64_t n, int32_t* ctl, double* fault, int vec, const SweepPlan& plan) {
@@ -1867,6 +1919,7 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
     madqp_ctx* ctx = s->ctx;
     const int64_t n = s->n;
     HIP_TRY(ctx, hipMemsetAsync(s->d_info, 0, sizeof(int32_t), ctx->stream));
+    s->upper_ok = false;
     // mid-size matrices: right-looking, two launches per 128-column block (chol_mid_step_kernel)
     // (measured on bench.py, m = 0.4 n, ms per iteration against the left-looking schedule: 3.34 / 3.90 at n = 3 000,
     // 6.37 / 7.51 at 5 000, 13.7 / 15.1 at 8 000, 22.7 / 23.2 at 10 000, 34.4 / 33.0 at 12 000 -- every step rewrites
@@ -1959,7 +2012,25 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
                 if (r) return r;
             }
         }
-        return invert_blocks(s, A, lda, 0, n);  // the inverse images of all blocks, one launch (factor-only diagonal kernels)
+        const int32_t ri = invert_blocks(s, A, lda, 0, n);  // the inverse images of all blocks, one launch (factor-only diagonal kernels)
+        if (ri) return ri;
+        // U = L' for the backward sweep (trsv_fwd_sweep_kernel<1, true>): one pass over the factor, 37 us at n = 5 000
+        static const bool upper_on = !(getenv("MADQP_SWEEP_UPPER") && atoi(getenv("MADQP_SWEEP_UPPER")) == 0);
+        if (upper_on && s->utmp && sweep_diag_mode() == 1) {
+            if (!s->upper) {
+                if (hipMalloc(&s->upper, (size_t)npad_m * npad_m * sizeof(double)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    s->upper = nullptr;
+                    return MADQP_OK;  // (no room for the copy: the backward sweep on L serves)
+                }
+                s->upper_ld = npad_m;
+            }
+            hipLaunchKernelGGL(lower_to_upper_kernel, dim3(2 * nblk, 2 * nblk), dim3(256), 0, ctx->stream, A, lda, n, s->upper,
+                               s->upper_ld);
+            LAUNCH_CHECK(ctx);
+            s->upper_ok = true;
+        }
+        return MADQP_OK;
     }
     // Quasi-definite mode (npos < n): A = [P, .; B, -Q] with P, Q positive definite and Q's block STORED AS +Q.
     // A = L diag(I, -I) L' with L = [L11, 0; W, L22], W = B L11^-T, L22 L22' = Q + W W': the same left-looking
@@ -2221,6 +2292,24 @@ extern "C" int32_t madqp_chol_solve(madqp_chol* s, double* rhs) {
     const double* A = s->A;
     if (n == 0) return MADQP_OK;
     ProfScope ps(ctx, MADQP_PROF_TRSV);
+    if (s->upper_ok) {  // mid-size factor: y = L^-1 b, then x = U^-1 y with the same kernel on U = L'; three launches
+        const int64_t nblk = (n + NB - 1) / NB;
+        const unsigned grid = s->d_jobs ? (unsigned)s->sweep_njobs : (unsigned)nblk;
+        double* yv = s->utmp;
+        double* xv = yv + nblk * NB;
+        double* part_f = xv + nblk * NB;
+        double* part_b = part_f + nblk * s->sweep_maxc * NB;
+        const SweepPlan pf{s->d_jobs, part_f, s->sweep_chunk, s->sweep_maxc}, pb{s->d_jobs, part_b, s->sweep_chunk, s->sweep_maxc};
+        double* fault = ctx->d_res + MADQP_FAULT_SLOT;
+        hipLaunchKernelGGL(sweep_prep_kernel, dim3((unsigned)std::min<int64_t>((s->utmp_len + 255) / 256, 256)), dim3(256), 0,
+                           ctx->stream, reinterpret_cast<unsigned long long*>(s->utmp), s->utmp_len, s->d_info);
+        hipLaunchKernelGGL((trsv_fwd_sweep_kernel<1, false>), dim3(grid), dim3(1024), 0, ctx->stream, A, lda, s->winv,
+                           (const double*)rhs, yv, n, s->d_info, fault, 1, pf, (double*)nullptr);
+        hipLaunchKernelGGL((trsv_fwd_sweep_kernel<1, true>), dim3(grid), dim3(1024), 0, ctx->stream, (const double*)s->upper,
+                           s->upper_ld, s->winv, (const double*)yv, xv, n, s->d_info, fault, 1, pb, rhs);
+        LAUNCH_CHECK(ctx);
+        return MADQP_OK;
+    }
     {
         // one launch per sweep (see trsv_*_sweep_kernel): y = L^-1 b into s->tmp, x = L^-T y into rhs
         const unsigned nblk = (unsigned)((n + NB - 1) / NB);

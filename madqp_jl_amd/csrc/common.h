@@ -226,4 +226,12 @@ struct madqp_chol {
     uint32_t* d_mid_plan;
     int32_t* mid_units;
     int32_t mid_plan_state;  // state: 0 not built, 1 in use, -1 no plan (the two-panel schedule runs)
+    // the backward sweep on U = L' (chol.hip, trsv_fwd_sweep_kernel<1, true>): U of the last mid-size factorisation (order
+    // npad, allocated at the first one), and the scratch of such a solve -- [y | x | partial sums of both sweeps], filled
+    // with the sentinel by one kernel per solve
+    double* upper;
+    int64_t upper_ld;
+    double* utmp;
+    int64_t utmp_len;
+    bool upper_ok;  // the last factorisation left U and substitution images
 };
