@@ -116,6 +116,8 @@ int32_t madqp_q_norm_inf3(madqp_ctx* ctx, int64_t len, const double* a, const do
                           int slot0);                                                           // 3 slots
 int32_t madqp_q_kkt_eval(madqp_kkt* k, const madqp_state* st, const double* q, const double* rhs, int slot0);  // 2
 int32_t madqp_q_kkt_factorize(madqp_kkt* k, int slot0);                                         // 1 slot: info
+// w = K^-1 p, optionally pcopy = p (kkt.hip: the condensed mode runs its per-variable passes fused)
+int32_t madqp_kkt_solve_from(madqp_kkt* k, const madqp_state* st, const double* p, double* w, double* pcopy);
 int32_t madqp_kkt_factor_result(madqp_kkt* k, int32_t info);
 int32_t madqp_chol_factor_q(madqp_chol* s, double* A, int64_t lda, double* d_slot);  // info -> *d_slot, no read-back
 void madqp_chol_factor_result(madqp_chol* s, int32_t info);                           // what the read-back said

@@ -67,6 +67,14 @@ struct madqp_kkt {
     int32_t refine;
     double *rf_p, *rf_r;
     int64_t rf_len;
+    // fused per-variable passes of the condensed mode (solve_pre_kernel / solve_post_kernel / resid_tail_kernel below):
+    // where each variable sits in the two bound lists (-1: not there), built when the lists are first seen, and the
+    // reduced right-hand side of the slacks kept between the two passes around the sweeps
+    int32_t *pos_lb, *pos_ub;
+    const int64_t *pos_key_lb, *pos_key_ub;
+    int64_t pos_nlb, pos_nub, pos_n;
+    double* rs;
+    bool fuse;  // MADQP_KKT_FUSE != 0
 };
 
 namespace {
@@ -79,6 +87,136 @@ inline int grid_for(int64_t len) {
 }
 
 #include "kkt_kernels.inc"
+
+// ---- fused per-variable passes of the condensed mode ---------------------------------------------------------------------
+// An iteration at n_x = 5 000 spent ~0.5 ms in ~100 launches of 2 us kernels that follow each other at the 4.7 us interval of
+// dependent dispatches.  Three runs of them -- in front of the sweeps, behind them, and the tail of the residual
+// p - K d -- touch each entry independently EXCEPT for the scatters of the bound lists into the variables
+// (reduce_rhs!, _kktmul!), which is why they were separate launches in list order.  With the inverse of the lists
+// (pos_lb / pos_ub: the place of a variable in each list) every variable gathers its two terms itself, in the order
+// the scatters applied them -- the same operations on the same operands, so the results are bitwise those of the
+// separate kernels (tests/test_gpu_solver.py compares the two forms; MADQP_KKT_FUSE=0 selects the separate ones).
+__global__ __launch_bounds__(TPB) void pos_fill_kernel(int64_t n, int32_t* __restrict__ a, int32_t* __restrict__ b) {
+    GRID_STRIDE(i, n) a[i] = b[i] = -1;
+}
+__global__ __launch_bounds__(TPB) void pos_scatter_kernel(int64_t cnt, const int64_t* __restrict__ ind, int32_t* __restrict__ pos) {
+    GRID_STRIDE(i, cnt) pos[ind[i]] = (int32_t)i;
+}
+// reduce_rhs! for one variable (src/kernels.jl:150-161 order: lower list, then upper list)
+__device__ __forceinline__ double reduced_rhs(const madqp_state& s, const double* __restrict__ p, int64_t j,
+                                              const int32_t* __restrict__ pos_lb, const int32_t* __restrict__ pos_ub) {
+    double v = p[j];
+    const int32_t pl = pos_lb[j], pu = pos_ub[j];
+    if (pl >= 0) v -= p[s.n + s.m + pl] / s.l_diag[pl];
+    if (pu >= 0) v -= p[s.n + s.m + s.nlb + pu] / s.u_diag[pu];
+    return v;
+}
+// w <- p with reduce_rhs! applied, t / u of condense_kernel, rs <- the reduced right-hand side of the slacks
+__global__ __launch_bounds__(TPB) void solve_pre_kernel(madqp_state s, const double* __restrict__ p, double* __restrict__ w,
+                                                        const int32_t* __restrict__ pos_lb, const int32_t* __restrict__ pos_ub,
+                                                        int64_t nx, const int64_t* __restrict__ slot,
+                                                        const double* __restrict__ theta, double* __restrict__ t,
+                                                        double* __restrict__ u, double* __restrict__ rs) {
+    int64_t L = s.n > s.m ? s.n : s.m;
+    if (s.nlb > L) L = s.nlb;
+    if (s.nub > L) L = s.nub;
+    GRID_STRIDE(i, L) {
+        if (i < s.n) {
+            const double v = reduced_rhs(s, p, i, pos_lb, pos_ub);
+            w[i] = v;
+            if (i >= nx) rs[i - nx] = v;
+        }
+        if (i < s.m) {
+            const int64_t k = slot[i];
+            double ti = p[s.n + i];
+            if (k >= 0) ti += reduced_rhs(s, p, nx + k, pos_lb, pos_ub) / s.pr_diag[nx + k];
+            t[i] = ti;
+            u[i] = theta[i] * ti;
+            w[s.n + i] = p[s.n + i];
+        }
+        if (i < s.nlb) w[s.n + s.m + i] = p[s.n + s.m + i];
+        if (i < s.nub) w[s.n + s.m + s.nlb + i] = p[s.n + s.m + s.nlb + i];
+    }
+}
+// decondense_kernel + finish_aug_solve_kernel (u holds A dx, w[0 .. nx) the solved dx), optionally pcopy <- p
+__global__ __launch_bounds__(TPB) void solve_post_kernel(madqp_state s, double* __restrict__ w, int64_t nx,
+                                                         const int64_t* __restrict__ slot, const int64_t* __restrict__ ind_ineq,
+                                                         const double* __restrict__ theta, const double* __restrict__ t,
+                                                         const double* __restrict__ u, const double* __restrict__ rs,
+                                                         const double* __restrict__ p, double* __restrict__ pcopy) {
+    int64_t L = s.n > s.m ? s.n : s.m;
+    if (s.nlb > L) L = s.nlb;
+    if (s.nub > L) L = s.nub;
+    double* wzl = w + s.n + s.m;
+    double* wzu = wzl + s.nlb;
+    auto dx_of = [&](int64_t j) {  // the entry of dx the separate kernels would read at j
+        if (j < nx) return w[j];
+        const int64_t k = j - nx, r = ind_ineq[k];
+        const double dy = theta[r] * (u[r] - t[r]);
+        return (rs[k] + dy) / s.pr_diag[nx + k];
+    };
+    GRID_STRIDE(i, L) {
+        if (i < s.m) {
+            const int64_t k = slot[i];
+            const double dy = theta[i] * (u[i] - t[i]);
+            w[s.n + i] = dy;
+            if (k >= 0) w[nx + k] = (rs[k] + dy) / s.pr_diag[nx + k];
+        }
+        if (i < s.nlb) wzl[i] = (-wzl[i] + s.l_lower[i] * dx_of(s.ind_lb[i])) / s.l_diag[i];
+        if (i < s.nub) wzu[i] = (wzu[i] - s.u_lower[i] * dx_of(s.ind_ub[i])) / s.u_diag[i];
+        if (pcopy) {
+            if (i < s.n) pcopy[i] = p[i];
+            if (i < s.m) pcopy[s.n + i] = p[s.n + i];
+            if (i < s.nlb) pcopy[s.n + s.m + i] = p[s.n + s.m + i];
+            if (i < s.nub) pcopy[s.n + s.m + s.nlb + i] = p[s.n + s.m + s.nlb + i];
+        }
+    }
+}
+// the tail of w = alpha K v + beta w behind the matrix products: jt_slack_kernel, mul_rows_kernel and the three passes of
+// _kktmul! (vec_kernels.inc) in one
+__global__ __launch_bounds__(TPB) void resid_tail_kernel(madqp_state s, double* __restrict__ w, const double* __restrict__ v,
+                                                         double alpha, double beta, int64_t nx,
+                                                         const int64_t* __restrict__ slot, const int64_t* __restrict__ ind_ineq,
+                                                         const double* __restrict__ u, const int32_t* __restrict__ pos_lb,
+                                                         const int32_t* __restrict__ pos_ub) {
+    int64_t L = s.n > s.m ? s.n : s.m;
+    if (s.nlb > L) L = s.nlb;
+    if (s.nub > L) L = s.nub;
+    double* wzl = w + s.n + s.m;
+    double* wzu = wzl + s.nlb;
+    const double* vzl = v + s.n + s.m;
+    const double* vzu = vzl + s.nlb;
+    GRID_STRIDE(i, L) {
+        if (i < s.n) {
+            double wi = w[i];
+            if (i >= nx) {  // jt_slack_kernel
+                const double val = alpha * (-v[s.n + ind_ineq[i - nx]]);
+                wi = (beta == 0.0) ? val : val + beta * wi;
+            }
+            wi += alpha * s.reg[i] * v[i];  // kktmul_diag_kernel
+            const int32_t pl = pos_lb[i], pu = pos_ub[i];
+            if (pl >= 0) wi -= alpha * vzl[pl];  // kktmul_lb_kernel
+            if (pu >= 0) wi += alpha * vzu[pu];  // kktmul_ub_kernel
+            w[i] = wi;
+        }
+        if (i < s.m) {
+            const int64_t k = slot[i];
+            double a = u[i];  // mul_rows_kernel
+            if (k >= 0) a -= v[nx + k];
+            double wy = (beta == 0.0) ? alpha * a : alpha * a + beta * w[s.n + i];
+            wy += alpha * s.du_diag[i] * v[s.n + i];
+            w[s.n + i] = wy;
+        }
+        if (i < s.nlb) {
+            const int64_t j = s.ind_lb[i];
+            wzl[i] = beta * wzl[i] + alpha * (v[j] * s.l_lower[i] - vzl[i] * s.l_diag[i]);
+        }
+        if (i < s.nub) {
+            const int64_t j = s.ind_ub[i];
+            wzu[i] = beta * wzu[i] + alpha * (v[j] * s.u_lower[i] + vzu[i] * s.u_diag[i]);
+        }
+    }
+}
 
 // Lower triangle of the augmented matrix, one 64 x 64 tile per workgroup (blockIdx.x = tile row, .y = tile column):
 //   rows/cols [0, nx): H + diag(dx);  [nx, np): identity (padding up to a block boundary);
@@ -270,6 +408,9 @@ extern "C" int32_t madqp_kkt_destroy(madqp_kkt* k) {
     if (k->sb) (void)hipFree(k->sb);
     if (k->rf_p) (void)hipFree(k->rf_p);
     if (k->rf_r) (void)hipFree(k->rf_r);
+    if (k->pos_lb) (void)hipFree(k->pos_lb);
+    if (k->pos_ub) (void)hipFree(k->pos_ub);
+    if (k->rs) (void)hipFree(k->rs);
     delete k;
     return MADQP_OK;
 }
@@ -296,6 +437,10 @@ static int32_t kkt_create_common(madqp_ctx* ctx, int mode, int64_t nx, int64_t m
     k->nx = nx;
     k->m = m;
     k->ns = ns;
+    {
+        const char* e_fuse = getenv("MADQP_KKT_FUSE");  // 0: the separate per-variable kernels (A/B tests)
+        k->fuse = !(e_fuse && e_fuse[0] == '0');
+    }
     k->H = H;
     k->ldh = ldh;
     k->A = A;
@@ -562,6 +707,73 @@ int32_t madqp_kkt_factor_result(madqp_kkt* k, int32_t info) {
 
 static int32_t kkt_solve_once(madqp_kkt* k, const madqp_state* st, double* w);
 
+// The fused passes serve the condensed mode with dense or sparse A, unscaled; the lists of st must be the ones the
+// inverse maps were made from (same pointers and lengths: the state layout is fixed while a KKT object lives,
+// include/madqp.h) -- they are made again when that changes.
+static bool kkt_fusable(const madqp_kkt* k) { return k->fuse && k->mode == KKT_CONDENSED && !k->scaled && k->m > 0; }
+static int32_t ensure_pos(madqp_kkt* k, const madqp_state* st) {
+    madqp_ctx* ctx = k->ctx;
+    if (k->pos_lb && k->pos_key_lb == st->ind_lb && k->pos_key_ub == st->ind_ub && k->pos_nlb == st->nlb &&
+        k->pos_nub == st->nub && k->pos_n == st->n)
+        return MADQP_OK;
+    if (k->pos_n != st->n || !k->pos_lb) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (k->pos_lb) (void)hipFree(k->pos_lb);
+        if (k->pos_ub) (void)hipFree(k->pos_ub);
+        if (k->rs) (void)hipFree(k->rs);
+        k->pos_lb = k->pos_ub = nullptr;
+        k->rs = nullptr;
+        const size_t nn = (size_t)std::max<int64_t>(st->n, 1);
+        if (hipMalloc(&k->pos_lb, nn * sizeof(int32_t)) != hipSuccess || hipMalloc(&k->pos_ub, nn * sizeof(int32_t)) != hipSuccess ||
+            hipMalloc(&k->rs, (size_t)std::max<int64_t>(k->ns, 1) * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            return madqp_fail(ctx, MADQP_ERR_ALLOC, "inverse bound lists (%lld variables)", (long long)st->n);
+        }
+    }
+    ARG_TRY(ctx, st->n < (int64_t)1 << 31 && st->nlb < (int64_t)1 << 31 && st->nub < (int64_t)1 << 31);
+    ProfScope ps(ctx, MADQP_PROF_VEC);
+    if (st->n) KLAUNCH(pos_fill_kernel, st->n, st->n, k->pos_lb, k->pos_ub);
+    if (st->nlb) KLAUNCH(pos_scatter_kernel, st->nlb, st->nlb, st->ind_lb, k->pos_lb);
+    if (st->nub) KLAUNCH(pos_scatter_kernel, st->nub, st->nub, st->ind_ub, k->pos_ub);
+    k->pos_key_lb = st->ind_lb;
+    k->pos_key_ub = st->ind_ub;
+    k->pos_nlb = st->nlb;
+    k->pos_nub = st->nub;
+    k->pos_n = st->n;
+    return MADQP_OK;
+}
+
+// w = K^-1 p (p untouched; w a different vector), optionally pcopy = p on the way: solve_system!'s copy, solve! and the
+// copy in front of its residual (src/linear_solver.jl:19-35) -- in the condensed mode with the per-variable passes fused
+int32_t madqp_kkt_solve_from(madqp_kkt* k, const madqp_state* st, const double* p, double* w, double* pcopy) {
+    int32_t r = check_kkt_state(k, st);
+    if (r) return r;
+    madqp_ctx* ctx = k->ctx;
+    ARG_TRY(ctx, p && w && p != w);
+    const int64_t len = st->n + st->m + st->nlb + st->nub;
+    if (!kkt_fusable(k) || k->refine > 0) {
+        if ((r = madqp_copy(ctx, len, p, w))) return r;
+        if ((r = madqp_kkt_solve(k, st, w))) return r;
+        return pcopy ? madqp_copy(ctx, len, p, pcopy) : MADQP_OK;
+    }
+    if ((r = ensure_pos(k, st))) return r;
+    k->u_is_A_of = nullptr;
+    const int64_t L = std::max(std::max(st->n, st->m), std::max(st->nlb, st->nub));
+    {
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        KLAUNCH(solve_pre_kernel, L, *st, p, w, k->pos_lb, k->pos_ub, k->nx, k->d_slot, k->theta, k->t, k->u, k->rs);
+    }
+    if ((r = apply_At(k, 1.0, k->u, 1.0, w))) return r;  // rhs_x = r1_x + A' (theta t)
+    if ((r = madqp_chol_solve(k->chol, w))) return r;
+    if ((r = apply_A(k, 1.0, w, 0.0, k->u))) return r;
+    {
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        KLAUNCH(solve_post_kernel, L, *st, w, k->nx, k->d_slot, k->d_ind_ineq, k->theta, k->t, k->u, k->rs, p, pcopy);
+    }
+    k->u_is_A_of = w;  // dx is final since the sweeps: u = A dx (madqp_kkt_mul_solved)
+    return MADQP_OK;
+}
+
 // Steps of iterative refinement INSIDE solve!: w = K^-1 p, then w += K^-1 (p - K w) -- for hosts whose loop is not ours.
 // MadIPM's solve_system! (src/linear_solver.jl:19-45) calls solve!(kkt, d) once and only LOOKS at the residual; the device
 // factorisation multiplies with explicit inverses of 16 x 16 sub-blocks where LAPACK substitutes scalar by scalar, which on
@@ -724,6 +936,14 @@ static int32_t kkt_mul_impl(madqp_kkt* k, const madqp_state* st, double* w, cons
     if (k->hdiag && nx) {
         ProfScope ps(ctx, MADQP_PROF_VEC);
         KLAUNCH(hdiag_axpy_kernel, nx, nx, alpha, k->hdiag, v, w);
+    }
+    if (kkt_fusable(k)) {  // the five per-variable passes that follow, in one (resid_tail_kernel)
+        if (!have_Av && (r = apply_A(k, 1.0, v, 0.0, k->u))) return r;
+        if ((r = ensure_pos(k, st))) return r;
+        const int64_t L = std::max(std::max(st->n, st->m), std::max(st->nlb, st->nub));
+        ProfScope ps(ctx, MADQP_PROF_VEC);
+        KLAUNCH(resid_tail_kernel, L, *st, w, v, alpha, beta, nx, k->d_slot, k->d_ind_ineq, k->u, k->pos_lb, k->pos_ub);
+        return MADQP_OK;
     }
     if (k->ns) {
         ProfScope ps(ctx, MADQP_PROF_VEC);

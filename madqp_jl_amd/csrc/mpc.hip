@@ -112,9 +112,7 @@ int32_t factorize_regularized_system(madqp_mpc* s, int first_trial = 0) {
 // src/linear_solver.jl:19-45
 int32_t solve_system(madqp_mpc* s) {
     const int64_t len = ntot(s->st);
-    TRY(madqp_copy(s->ctx, len, s->st.p, s->st.d));
-    TRY(madqp_kkt_solve(s->kkt, &s->st, s->st.d));
-    TRY(madqp_copy(s->ctx, len, s->st.p, s->w1));
+    TRY(madqp_kkt_solve_from(s->kkt, &s->st, s->st.p, s->st.d, s->w1));   // d = K^-1 p, w1 = p
     TRY(madqp_kkt_mul_solved(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));  // d: the solve's result, untouched
     for (int32_t it = 0; it < s->opt.refine_steps; ++it) {  // extension (off by default): d += K^-1 (p - K d)
         TRY(madqp_kkt_solve(s->kkt, &s->st, s->w1));
@@ -411,9 +409,7 @@ int32_t body_sequential(madqp_mpc* s, madqp_mpc_info* info_host) {
 // solve_system! up to its reduction: d = K^-1 p, w1 = p - K d, the three norms into the result block at slot0
 int32_t solve_system_queue(madqp_mpc* s, int slot0) {
     const int64_t len = ntot(s->st);
-    TRY(madqp_copy(s->ctx, len, s->st.p, s->st.d));
-    TRY(madqp_kkt_solve(s->kkt, &s->st, s->st.d));
-    TRY(madqp_copy(s->ctx, len, s->st.p, s->w1));
+    TRY(madqp_kkt_solve_from(s->kkt, &s->st, s->st.p, s->st.d, s->w1));  // d = K^-1 p, w1 = p
     TRY(madqp_kkt_mul_solved(s->kkt, &s->st, s->w1, s->st.d, -1.0, 1.0));
     for (int32_t it = 0; it < s->opt.refine_steps; ++it) {  // the refinement steps of solve_system, queued like the rest
         TRY(madqp_kkt_solve(s->kkt, &s->st, s->w1));

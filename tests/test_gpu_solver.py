@@ -330,6 +330,42 @@ def test_native_driver_is_bitwise_the_python_driver(hip):
         s.close()
 
 
+def test_fused_per_variable_passes_are_bitwise_the_separate_kernels(hip):
+    """csrc/kkt.hip, solve_pre_kernel / solve_post_kernel / resid_tail_kernel: reduce_rhs! + the condensation, its inverse +
+    finish_aug_solve!, and the tail of _kktmul! each run as ONE kernel in which a variable gathers its terms through the
+    inverse of the bound lists, in the order the scatters applied them -- same operations, same operands, same bits as the
+    separate kernels (MADQP_KKT_FUSE=0), with bounds on slacks, variables in both lists, equality rows and Gondzio
+    corrections in play."""
+    import os
+
+    def run(qp, fuse, **kw):
+        os.environ["MADQP_KKT_FUSE"] = "1" if fuse else "0"
+        try:
+            s = M.MPCSolver(to_device(qp, hip), hip, driver="native", **kw)  # (read when the KKT object is created)
+            r = s.solve()
+            s.close()
+        finally:
+            os.environ.pop("MADQP_KKT_FUSE", None)
+        return r
+
+    both = Q.synthetic_qp(91, 150, 60)  # every variable in BOTH bound lists, half of the rows equalities
+    both.lvar[:] = -1.0 - np.arange(both.lvar.size) % 3
+    both.uvar[:] = 1.0 + np.arange(both.uvar.size) % 2
+    both.lcon[::2] = both.ucon[::2]
+    cases = ((Q.synthetic_qp(77, 200, 80), dict(max_ncorr=3)),
+             (Q.synthetic_qp(78, 120, 50, "lp"), dict(regularization=M.AdaptiveRegularization(1e-8, -1e-9, 1e-9))),
+             (Q.dummy_qp(20, 15, equality_cons=(0, 1, 2, 7)),
+              dict(step_rule=M.MehrotraAdaptiveStep(0.99), regularization=M.FixedRegularization(1e-8, -1e-8))),
+             (both, dict(max_ncorr=2, regularization=M.FixedRegularization(1e-8, -1e-8))),
+             (Q.synthetic_qp(79, 140, 60, "lp"), dict(refine_steps=1)))
+    for qp, kw in cases:
+        a, b = run(qp, False, **kw), run(qp, True, **kw)
+        assert a["status"] == b["status"] and a["iter"] == b["iter"] and a["trace"] == b["trace"]
+        assert np.array_equal(a["solution"], b["solution"]) and a["objective"] == b["objective"]
+        assert np.array_equal(a["multipliers"], b["multipliers"])
+        assert np.array_equal(a["multipliers_L"], b["multipliers_L"]) and np.array_equal(a["multipliers_U"], b["multipliers_U"])
+
+
 def test_fused_iteration_is_bitwise_the_sequential_one_with_two_readbacks(hip):
     """csrc/mpc.hip, body_fused: the reductions of an iteration are queued in the result block and read back twice
     (after the corrector, which also decides the first Gondzio trial; after the update + the next termination test;
