@@ -37,7 +37,7 @@ def test_generator_bit_exact(hip):
 
 
 @pytest.mark.parametrize("rows,cols", [(1, 1), (5, 3), (64, 130), (257, 1000), (3000, 77), (128, 5000),
-                                       (2500, 2049)])
+                                       (2500, 2049), (71, 2061), (2000, 5000)])  # (the last four: one-pass strips for A' x)
 @pytest.mark.parametrize("trans", [0, 1])
 def test_gemv(hip, rows, cols, trans):
     rng = np.random.default_rng(rows * 1000 + cols + trans)
