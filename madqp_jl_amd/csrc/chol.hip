@@ -619,6 +619,33 @@ __device__ __forceinline__ double sweep_poll_one(const double* p, double* __rest
     return __longlong_as_double(u);
 }
 
+// The partial sums of a block's other jobs for the lane's two entries, added in job order.  Up to four jobs' words are
+// requested at once: one after the other, each an L2 round trip of ~1 us, they were half of a hop at n = 50 000 (six
+// jobs per block row: 6.2 us per hop where n = 5 000, one job per row, takes 3.2).
+__device__ __forceinline__ void sweep_far2(const double* __restrict__ pp, int c, int lane, double* __restrict__ err,
+                                           double& f0, double& f1) {
+    f0 = f1 = 0.0;
+    for (int c0 = 0; c0 < c; c0 += 4) {
+        unsigned long long u[4][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c0 + k < c) {
+                u[k][0] = ld_sc1_u64(pp + (int64_t)(c0 + k) * NB + lane);
+                u[k][1] = ld_sc1_u64(pp + (int64_t)(c0 + k) * NB + 64 + lane);
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c0 + k < c) {
+                const double a = (u[k][0] == SWEEP_SENTINEL) ? sweep_poll_one(pp + (int64_t)(c0 + k) * NB + lane, err)
+                                                             : __longlong_as_double(u[k][0]);
+                const double b = (u[k][1] == SWEEP_SENTINEL) ? sweep_poll_one(pp + (int64_t)(c0 + k) * NB + 64 + lane, err)
+                                                             : __longlong_as_double(u[k][1]);
+                f0 += a;
+                f1 += b;
+            }
+    }
+}
+
 // half a 128 x 128 column-major tile: rows 2*lane, 2*lane+1 and the 4 columns of this wave
 __device__ __forceinline__ void sweep_load_half(const double* __restrict__ base, int64_t ld, bool ok0,
                                                 bool ok1, bool vec, double2_t (&dst)[4]) {
@@ -931,11 +958,8 @@ __global__ __launch_bounds__(1024) void trsv_fwd_sweep_kernel(const double* __re
         s0 += red[q][lane];
         s1 += red[q][64 + lane];
     }
-    double far0 = 0.0, far1 = 0.0;  // the partial sums of this block's other jobs, in column order
-    for (int cc = 0; cc < c; ++cc) {
-        far0 += sweep_poll_one(plan.part + ((int64_t)rl * plan.maxc + cc) * NB + lane, fault);
-        far1 += sweep_poll_one(plan.part + ((int64_t)rl * plan.maxc + cc) * NB + 64 + lane, fault);
-    }
+    double far0, far1;  // the partial sums of this block's other jobs, in column order
+    sweep_far2(plan.part + (int64_t)rl * plan.maxc * NB, c, lane, fault, far0, far1);
     const double u0 = lane < w ? b0 - (far0 + s0) : 0.0, u1 = 64 + lane < w ? b1 - (far1 + s1) : 0.0;
     const double2_t z = REV ? sweep_diag_bwd<DIAG>(ximg, lane, u0, u1) : sweep_diag_fwd<DIAG>(ximg, lane, u0, u1);
     if (lane < w) st_sc1_f64(y + row0 + lane, z.x);
@@ -1098,11 +1122,8 @@ __global__ __launch_bounds__(1024) void trsv_bwd_sweep_kernel(const double* __re
         return;
     }
     if (wave != 0) return;  // wave 0 alone from here, no further barrier
-    double far0 = 0.0, far1 = 0.0;
-    for (int cc = 0; cc < c; ++cc) {
-        far0 += sweep_poll_one(plan.part + ((int64_t)rr * plan.maxc + cc) * NB + lane, fault);
-        far1 += sweep_poll_one(plan.part + ((int64_t)rr * plan.maxc + cc) * NB + 64 + lane, fault);
-    }
+    double far0, far1;
+    sweep_far2(plan.part + (int64_t)rr * plan.maxc * NB, c, lane, fault, far0, far1);
     const double u0 = lane < w ? y0 - (far0 + vs[lane]) : 0.0, u1 = 64 + lane < w ? y1 - (far1 + vs[64 + lane]) : 0.0;
     const double2_t z = sweep_diag_bwd<DIAG>(ximg, lane, u0, u1);
     if (lane < w) st_sc1_f64(x + col0 + lane, z.x);

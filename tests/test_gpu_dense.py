@@ -142,16 +142,19 @@ def test_cholesky_factor_and_solve(hip, n, padded):
         hip.chol_destroy(h)
 
 
-@pytest.mark.parametrize("n,chunk", [(1100, 2), (1100, 3), (2300, 5), (700, 1)])
-def test_sweeps_with_split_block_rows(hip, n, chunk):
+@pytest.mark.parametrize("n,chunk,padded", [(1100, 2, False), (1100, 3, False), (2300, 5, False), (700, 1, False),
+                                            (1100, 2, True), (2300, 5, True), (700, 1, True), (1153, 3, True)])
+def test_sweeps_with_split_block_rows(hip, n, chunk, padded):
     """Block rows longer than MADQP_SWEEP_CHUNK tiles are streamed by several workgroups (chol.hip, SweepPlan; 64 tiles
     by default, i.e. only beyond n = 8 320).  A small chunk puts the same code under a case the CPU can check: the
-    solution must agree with the one-job-per-row sweep to rounding (the partial sums are added in another order)."""
+    solution must agree with the one-job-per-row sweep to rounding (the partial sums are added in another order).
+    padded: the layout of the mid-size factorisation, whose backward sweep is the forward kernel on U = L' with the
+    blocks -- and the jobs of a split block row -- taken from the far end (trsv_fwd_sweep_kernel<1, true>)."""
     import os
     rng = np.random.default_rng(n + chunk)
     K = _spd(n, rng)
     K = 0.5 * (K + K.T)
-    lda = n + 2
+    lda = (n + 127) // 128 * 128 + 2 if padded else n + 2
     host = np.zeros((n, lda))
     host[:, :n] = K.T
     b = rng.standard_normal(n)
