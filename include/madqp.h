@@ -490,7 +490,9 @@ int32_t madqp_mpc_head(madqp_mpc* mpc, madqp_mpc_info* info_host, int32_t* statu
  * iterates, the model evaluation and the next termination test's norms are queued behind it as kernels that do
  * nothing when that verdict is "the host takes over" (failed factorisation, failed verdict, a further trial); before
  * the second fetch the NEXT iteration's diagonal and KKT assembly are queued (K is rebuilt from scratch every
- * iteration, so a loop that ends there has lost nothing but that assembly).  The host checks every decision of the
+ * iteration, so a loop that ends there has lost nothing but that assembly).  Where the host takes over -- and where the
+ * call returns MADQP_NUM_NAN -- x, y, zl, zu and the bounds are as they were when the call began; f, c and A'y have
+ * been re-evaluated at that same x (the values they had, for any state the loop itself produced).  The host checks every decision of the
  * device against its own and fails with MADQP_ERR_HIP should they differ.  MADQP_MPC_AHEAD=0 at creation: the round-4
  * form, nothing queued behind a fetch.  The residual norms of the next termination test come with the second fetch,
  * so madqp_mpc_head behind a body does not synchronise at all. */

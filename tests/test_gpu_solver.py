@@ -330,6 +330,44 @@ def test_native_driver_is_bitwise_the_python_driver(hip):
         s.close()
 
 
+def test_a_failed_verdict_behind_a_queued_update_leaves_the_iterates_where_they_were(hip):
+    """csrc/mpc.hip, body_fused queued ahead: from the second pass on the update of the iterates is already queued when the
+    host reads the corrector's block -- as kernels that do nothing unless the device's own verdict (mpc_decide_kernel) was
+    "go on".  A NaN that appears in a LATER pass must therefore surface as in the waiting form: SolveException, with the
+    iterates x, y, zl, zu and the bounds as they were when the pass began (src/linear_solver.jl:41-43 throws before
+    src/solver.jl:332-335 moves anything).  (f, c and A'y are re-evaluated at that same x by the queued kernels: the same
+    values for any state the loop itself produced.)"""
+    import os
+
+    def run(ahead):
+        os.environ["MADQP_MPC_AHEAD"] = "1" if ahead else "0"
+        try:
+            s = M.MPCSolver(to_device(Q.synthetic_qp(79, 60, 20), hip), hip, driver="native",
+                            regularization=M.FixedRegularization(1e-8, -1e-8))
+            s.initialize()
+        finally:
+            os.environ.pop("MADQP_MPC_AHEAD", None)
+        for _ in range(3):
+            assert s.iteration_head() is None
+            s.iteration_body()
+        assert s.iteration_head() is None
+        s.st.x[3] = float("nan")  # K and both right-hand sides carry it: the solves of the pass fail their verdict
+        snap = {k: getattr(s.st, k).clone() for k in ("x", "y", "zl", "zu", "xl", "xu")}
+        with pytest.raises(M.SolveException):
+            s.iteration_body()
+        torch.cuda.synchronize()
+        fill = lambda t: torch.nan_to_num(t, nan=-12345.0)
+        same = {k: bool(torch.equal(fill(getattr(s.st, k)), fill(v))) for k, v in snap.items()}
+        stats = hip.mpc_ahead_stats(s._native)
+        s.close()
+        return same, stats
+
+    for ahead in (False, True):
+        same, stats = run(ahead)
+        assert all(same.values()), (ahead, same)
+        assert (stats[0] > 0) == ahead
+
+
 def test_fused_per_variable_passes_are_bitwise_the_separate_kernels(hip):
     """csrc/kkt.hip, solve_pre_kernel / solve_post_kernel / resid_tail_kernel: reduce_rhs! + the condensation, its inverse +
     finish_aug_solve!, and the tail of _kktmul! each run as ONE kernel in which a variable gathers its terms through the
