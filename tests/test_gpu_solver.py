@@ -95,7 +95,7 @@ def test_known_answers(hip):
 
 
 @DRIVERS
-@pytest.mark.parametrize("n,m,ncorr", [(300, 120, 0), (300, 120, 3), (1500, 600, 0)])
+@pytest.mark.parametrize("n,m,ncorr", [(300, 120, 0), (300, 120, 3), (1500, 600, 0), (2500, 700, 3)])  # (the last: 20 blocks, one-pass A'x, Gondzio)
 def test_synthetic_vs_oracle(hip, n, m, ncorr, driver):
     qp = Q.synthetic_qp(20250614 + n, n, m)
     ref = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8),
