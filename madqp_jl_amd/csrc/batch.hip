@@ -55,6 +55,7 @@ struct BQ {  // device view of the batch (by value in the kernel arguments); pro
     // solve's residual check formed -- H dx and A' dy, unscaled -- per problem (nx each); nullptr: every iteration
     // evaluates H x, A x and A' y with passes of their own.  incr_ok[b]: the products belong to the step just taken.
     double *hx, *raw_h, *raw_at;
+    double* at;  // A' dy of the LAST condensed solve, formed in the pass that formed A dx (batch_wg.inc: wg_gemv_n_then_t); nx each
     int32_t* incr_ok;
     double* scal;
     int32_t *status, *iters, *info, *retry_skip;
@@ -98,7 +99,7 @@ __device__ __forceinline__ madqp_state state_of(const BQ& q, int64_t b) {
 struct Prob {
     const double *H, *A, *qv, *rhs;
     double *theta, *t, *u, *K, *S, *winv, *tmp, *tn, *w1, *scal, *sym;
-    double *hx, *raw_h, *raw_at;
+    double *hx, *raw_h, *raw_at, *at;
     double c0;
 };
 __device__ __forceinline__ Prob prob_of(const BQ& q, int64_t b) {
@@ -119,6 +120,7 @@ __device__ __forceinline__ Prob prob_of(const BQ& q, int64_t b) {
     p.hx = q.hx ? q.hx + b * q.nx : nullptr;
     p.raw_h = q.hx ? q.raw_h + b * q.nx : nullptr;
     p.raw_at = q.hx ? q.raw_at + b * q.nx : nullptr;
+    p.at = q.at ? q.at + b * q.nx : nullptr;
     p.w1 = q.w1 + b * q.ntot;
     p.scal = q.scal + b * S_COUNT;
     p.c0 = q.c0[b];
@@ -345,6 +347,10 @@ extern "C" int32_t madqp_batch_create(madqp_ctx* ctx, int64_t B, int64_t nx, int
             BALLOC(q.raw_at, B * nx, true);
         }
         BALLOC(q.incr_ok, B, true);
+        // A dx and A' dy of a condensed solve in ONE pass over A (the workgroup programs are HBM bound; the residual check
+        // of solve_system! then has no pass of its own over A): needs a row of A in a wave's registers, nx <= 512
+        static const bool nt = !(getenv("MADQP_BATCH_NT") && atoi(getenv("MADQP_BATCH_NT")) == 0);
+        if (nt && !normal && nx > 0 && nx <= 512 && m > 0) BALLOC(q.at, B * nx, true);
     }
     BALLOC(q.scal, B * S_COUNT, true);
     BALLOC(q.status, B, true);
