@@ -147,6 +147,9 @@ typedef struct madqp_state {
     int64_t n, m, nlb, nub;
     const int64_t* ind_lb; /* nlb, 0-based, strictly increasing */
     const int64_t* ind_ub; /* nub */
+    /* (The two lists are the problem's bound pattern: their CONTENTS do not change while a KKT object that has seen
+     * them lives -- the condensed KKT system keeps their inverse, csrc/kkt.hip: ensure_pos, keyed on the pointers and
+     * lengths; hand a different pattern over in different arrays.) */
     double *x, *xl, *xu, *zl, *zu, *f; /* n */
     double *y, *c;                     /* m */
     double* jacl;                      /* n */
