@@ -24,6 +24,18 @@ from .options import (AdaptiveRegularization, AdaptiveStep, ConservativeStep, Fi
                       IPMOptions, MehrotraAdaptiveStep, NoRegularization)
 from .qp import DeviceCSR, DeviceQP
 
+
+def _fdiv(a: float, b: float) -> float:
+    """IEEE division of two host scalars, as Julia's ``/`` on Float64 (x / 0 = +-Inf, 0 / 0 = NaN): the reference's loop
+    forms such quotients without a guard -- the start point's 0 / 0 when a problem has no bound at all
+    (src/solver.jl:93-94), a step length against a zero direction component (src/kernels.jl:341-368) -- and goes on;
+    Python's float division raises instead."""
+    if b != 0.0:
+        return a / b
+    if a == 0.0 or a != a:
+        return float("nan")
+    return math.copysign(float("inf"), a) * math.copysign(1.0, b)
+
 SOLVE_SUCCEEDED = 1
 MAXIMUM_ITERATIONS_EXCEEDED = 6
 ERROR_IN_STEP_COMPUTATION = -3
@@ -237,7 +249,7 @@ class MPCSolver:
         has_inequalities = (self.nlb + self.nub) > 0
         mu_curr = self.be.get_complementarity_measure(self.st)
         if has_inequalities:
-            t = mu_affine / mu_curr
+            t = _fdiv(mu_affine, mu_curr)
             sigma = min(max(t * t * t, 1e-6), 10.0)  # t^3 as Julia's literal power forms it (and csrc/mpc.hip, mpc_mu_kernel)
         else:
             sigma = 1.0
@@ -284,19 +296,19 @@ class MPCSolver:
         if max_ap < 1.0:
             x, bnd, z, dxi, dzi = vals["p"]
             if axl <= axu:
-                tmp = mu_full / (z + max_ad * dzi)
-                alpha_p = (x - bnd - tmp) / (-dxi)
+                tmp = _fdiv(mu_full, z + max_ad * dzi)
+                alpha_p = _fdiv(x - bnd - tmp, -dxi)
             else:
-                tmp = mu_full / (z + max_ad * dzi)
-                alpha_p = (bnd - x - tmp) / dxi
+                tmp = _fdiv(mu_full, z + max_ad * dzi)
+                alpha_p = _fdiv(bnd - x - tmp, dxi)
         if max_ad < 1.0:
             x, bnd, z, dxi, dzi = vals["d"]
             if azl <= azu:
-                tmp = mu_full / (x + max_ap * dxi - bnd)
-                alpha_d = -(z - tmp) / dzi
+                tmp = _fdiv(mu_full, x + max_ap * dxi - bnd)
+                alpha_d = _fdiv(-(z - tmp), dzi)
             else:
-                tmp = mu_full / (bnd - x - max_ap * dxi)
-                alpha_d = -(z - tmp) / dzi
+                tmp = _fdiv(mu_full, bnd - x - max_ap * dxi)
+                alpha_d = _fdiv(-(z - tmp), dzi)
         self.alpha_p = max(alpha_p, rule.gamma_f * max_ap)
         self.alpha_d = max(alpha_d, rule.gamma_f * max_ad)
 
@@ -331,8 +343,10 @@ class MPCSolver:
             mu += s[0] - s[1]
         if self.nub > 0:
             mu += s[2] - s[3]
-        delta_x2 = mu / (2 * (s[4] + s[5]))
-        delta_s2 = mu / (2 * (s[6] + s[7]))
+        # (IEEE division as Julia's: with no bound at all both are 0 / 0 = NaN, added to EMPTY views at :96-99 -- the
+        # reference goes on; Python's float division would raise)
+        delta_x2 = _fdiv(mu, 2 * (s[4] + s[5]))
+        delta_s2 = _fdiv(mu, 2 * (s[6] + s[7]))
         be.sp_shift(st, delta_x2, delta_s2)  # :96-99
         be.sp_project(st, self.opt.bound_fac)  # :101-118
         if not be.sp_check(st):  # :120-123

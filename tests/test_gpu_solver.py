@@ -330,6 +330,33 @@ def test_native_driver_is_bitwise_the_python_driver(hip):
         s.close()
 
 
+@DRIVERS
+def test_equality_constrained_qp_without_any_bound(hip, driver):
+    """No bound on any variable, every row an equality: both bound lists are empty (nlb = nub = 0, no slacks) -- the edge
+    the fused per-variable passes (inverse lists of length n, all -1), the device-side decisions of the queued-ahead loop
+    (step lengths from alpha_none_kernel, complementarity sums over nothing) and update_barrier!'s "any bound" rule all
+    have to get right; and the start point's 0 / 0 (src/solver.jl:93-94: NaN shifts added to EMPTY views, where Python's
+    float division would raise).  The condensed matrix of an all-equality problem is H + 1e8 A'A: the second iterate's dual
+    residual is the conditioning noise of that solve, 4e-8 or 2e-10 depending on whether it is refined -- one iteration
+    more or less.  So like is compared with like: the default library (AUTO refinement at this size) against the oracle
+    with one refinement step, refine_steps = 0 against the plain oracle's count."""
+    import parity
+
+    qp = Q.synthetic_qp(123, 60, 20)
+    qp.lvar[:], qp.uvar[:] = -np.inf, np.inf
+    qp.ucon[:] = qp.lcon[:] = 0.25
+    oreg = mpc.FixedRegularization(1e-8, -1e-8)
+    ref = parity.oracle_execution(qp, "refine", regularization=oreg)
+    r = solve_hip(qp, hip, driver=driver)
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"]
+    compare_traces(r["trace"], ref["trace"], "no bounds")
+    assert close(r["objective"], ref["objective"], 1e-9)
+    assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
+    plain, r0 = mpc.solve(qp, kkt_system="condensed", regularization=oreg), solve_hip(qp, hip, driver=driver, refine_steps=0)
+    assert r0["status"] == plain["status"] == M.SOLVE_SUCCEEDED and r0["iter"] == plain["iter"]
+    assert np.max(np.abs(r0["solution"] - plain["solution"])) <= 1e-7
+
+
 def test_a_failed_verdict_behind_a_queued_update_leaves_the_iterates_where_they_were(hip):
     """csrc/mpc.hip, body_fused queued ahead: from the second pass on the update of the iterates is already queued when the
     host reads the corrector's block -- as kernels that do nothing unless the device's own verdict (mpc_decide_kernel) was

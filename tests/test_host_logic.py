@@ -288,3 +288,18 @@ def test_refinement_auto_rule_is_resolved_by_the_order_of_the_factorised_matrix(
     r = make(qp, regularization=reg).solve()
     ref = mpc.solve(qp, kkt_system="condensed", regularization=mpc.FixedRegularization(1e-8, -1e-8), refine_steps=1)
     assert r["iter"] == ref["iter"] and np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-9
+
+
+def test_host_quotients_follow_ieee_like_the_reference():
+    """The reference's loop divides host scalars without a guard -- the start point's 0 / 0 when a problem has no bound at
+    all (src/solver.jl:93-94: the NaN is then added to EMPTY views), a step length against a zero direction component
+    (src/kernels.jl:341-368) -- and Julia's Float64 division returns NaN / +-Inf where Python's raises: the host driver
+    divides through this helper."""
+    import math
+
+    from madqp_jl_amd.solver import _fdiv
+
+    assert math.isnan(_fdiv(0.0, 0.0)) and math.isnan(_fdiv(float("nan"), 0.0)) and math.isnan(_fdiv(0.0, -0.0))
+    assert _fdiv(1.0, 0.0) == float("inf") and _fdiv(-2.5, 0.0) == -float("inf")
+    assert _fdiv(1.0, -0.0) == -float("inf") and _fdiv(-1.0, -0.0) == float("inf")
+    assert _fdiv(3.0, 2.0) == 1.5 and _fdiv(-1e-300, 1e300) == -1e-300 / 1e300
