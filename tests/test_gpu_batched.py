@@ -182,3 +182,39 @@ def test_batched_normal_equations(hip):
     assert r["status"] == M.SOLVE_SUCCEEDED and abs(r["objective"] - 1.0) < 1e-8 and np.allclose(r["solution"], [0.5, 0.5], atol=1e-8)
     with pytest.raises(ValueError):  # a QP: NormalKKTSystem supports only linear programs
         M.BatchedMPCSolver([to_device(Q.synthetic_qp(1, 20, 8), hip)], hip, kkt_system="normal", regularization=reg)
+
+
+def _edge_batch(case, B=3):
+    qps = []
+    for i in range(B):
+        qp = Q.synthetic_qp(700 + 11 * i, 40, 15)
+        if case == "lower_bounds_only":  # nub = 0 on the variables, rows bounded below only
+            qp.uvar[:] = np.inf
+            qp.ucon[:] = np.inf
+        elif case == "upper_bounds_only":
+            qp.lvar[:] = -np.inf
+            qp.lcon[:] = -np.inf
+            qp.x0[:] = 0.5
+        elif case == "mixed":  # free, lower-only, upper-only and boxed variables; equality, one-sided and ranged rows
+            qp.lvar[0::4], qp.uvar[0::4] = -np.inf, np.inf
+            qp.uvar[1::4] = np.inf
+            qp.lvar[2::4] = -np.inf
+            qp.ucon[0::3] = qp.lcon[0::3] = 0.1
+            qp.ucon[1::3] = np.inf
+        elif case == "no_bounds":  # both bound lists empty, every row an equality (the start point's 0 / 0, src/solver.jl:93-94)
+            qp.lvar[:], qp.uvar[:] = -np.inf, np.inf
+            qp.ucon[:] = qp.lcon[:] = 0.25
+        qps.append(qp)
+    return qps
+
+
+@pytest.mark.parametrize("case", ["lower_bounds_only", "upper_bounds_only", "mixed", "no_bounds"])
+def test_batched_edge_shapes(hip, case):
+    """The edges of the index lists through the lock-step engine: an empty upper or lower list, one-sided rows, every kind of
+    variable and row at once, and no bound at all (nlb = nub = 0: the workgroup programs' loops over the lists run zero
+    times, the start point divides 0 by 0 and adds the NaN to nothing) -- problem by problem against the oracle."""
+    qps = _edge_batch(case)
+    s = M.BatchedMPCSolver([to_device(q, hip) for q in qps], hip, regularization=REG)
+    res = s.solve()
+    s.close()
+    check_against_oracle(qps, res)
