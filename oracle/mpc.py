@@ -721,8 +721,9 @@ class MPCSolver:
             mu += x[ilb] @ self.zl[ilb] - l[ilb] @ self.zl[ilb]  # :87
         if self.nub > 0:
             mu += u[iub] @ self.zu[iub] - x[iub] @ self.zu[iub]  # :90
-        delta_x2 = mu / (2 * (np.sum(self.zl[ilb]) + np.sum(self.zu[iub])))  # :93
-        delta_s2 = mu / (2 * (np.sum(x[ilb] - l[ilb]) + np.sum(u[iub] - x[iub])))  # :94
+        with np.errstate(invalid="ignore", divide="ignore"):  # no bound at all: 0 / 0 = NaN, as in Julia, added to empty views below
+            delta_x2 = np.float64(mu) / (2 * (np.sum(self.zl[ilb]) + np.sum(self.zu[iub])))  # :93
+            delta_s2 = np.float64(mu) / (2 * (np.sum(x[ilb] - l[ilb]) + np.sum(u[iub] - x[iub])))  # :94
         x[ilb] += delta_x2  # :96
         x[iub] -= delta_x2  # :97
         self.zl[ilb] += delta_s2

@@ -341,3 +341,25 @@ def test_k25_conformance_and_bounded_entries(hip):
     res = np.max(np.abs(st.w1.cpu().numpy() - b)) / max(1.0, np.max(np.abs(b)))
     assert res <= max(10.0 * res_oracle, 1e-10), (res, res_oracle)
     s.close()
+
+
+@DRIVERS
+@pytest.mark.parametrize("form", ["augmented", "scaled_augmented"])
+@pytest.mark.parametrize("case", ["lower_bounds_only", "upper_bounds_only", "one_by_one", "mixed", "no_bounds"])
+def test_edge_shapes_through_the_augmented_forms(hip, case, form, driver):
+    """tests/edge_cases.py through K2 and K2.5 with the reference's default regularization (delta_d = 0: equality rows
+    exact): an empty upper or lower list, one-sided rows, a 1 x 1 problem, everything at once, and no bound at all --
+    where the augmented matrix is the plain saddle-point system [H, A'; A, 0] and the condensed form's 1e8 A'A does not
+    arise.  Against the oracle's own K2 / K2.5 paths."""
+    from edge_cases import edge_qp
+
+    qp = edge_qp(case)
+    ref = mpc.solve(qp, kkt_system="K2" if form == "augmented" else "K2.5")
+    s = M.MPCSolver(to_device(qp, hip), hip, kkt_system=form, driver=driver)
+    r = s.solve()
+    s.close()
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED, (r["status"], ref["status"])
+    assert r["iter"] == ref["iter"], (case, form, r["iter"], ref["iter"])
+    compare_traces(r["trace"], ref["trace"], f"{form} {case}")
+    assert close(r["objective"], ref["objective"], 1e-9)
+    assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7

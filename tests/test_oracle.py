@@ -297,3 +297,22 @@ def test_blocking_index_on_an_exact_tie_is_the_last_one():
             assert vals[i] == min(vals) and all(v > vals[i] for v in vals[i + 1:])
         else:
             assert i == -1
+
+
+def test_oracle_on_the_edge_shapes():
+    """tests/edge_cases.py on the CPU: the oracle reaches SOLVE_SUCCEEDED on every shape the GPU suites then hold the device
+    against -- no constraint row, an empty bound list, one-sided rows, 1 x 1, everything mixed, and no bound at all, where
+    the start point's 0 / 0 (src/solver.jl:93-94) is a NaN added to empty views, silently, as in Julia."""
+    import warnings
+
+    from edge_cases import EDGE_CASES, edge_qp
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for case in EDGE_CASES:
+            qp = edge_qp(case)
+            for form, reg in (("condensed", mpc.FixedRegularization(1e-8, -1e-8)), ("K2", None)):
+                kw = dict(regularization=reg) if reg is not None else {}
+                r = mpc.solve(qp, kkt_system=form, **kw)
+                assert r["status"] == mpc.SOLVE_SUCCEEDED, (case, form, r["status"])
+                assert np.all(np.isfinite(r["solution"])) and np.isfinite(r["objective"])
