@@ -242,3 +242,25 @@ def test_benchmark_loop_over_instance_files(hip, tmp_path):
     assert abs(rows["hs21.qps"][6] + 99.96) < 1e-6
     lines = open(out).read().splitlines()
     assert len(lines) == 5 and all(len(l.split("\t")) == 10 for l in lines)
+
+
+@pytest.mark.parametrize("case", ["lower_bounds_only", "upper_bounds_only", "one_by_one", "mixed", "no_bounds"])
+def test_edge_shapes_with_a_sparse_jacobian(hip, case):
+    """tests/edge_cases.py with the Jacobian held as CSR (the sparse front end of the condensed system: SpMV for A, A',
+    the Gram matrix from the sparse rows) -- the fused per-variable passes serve this form too -- against the oracle with
+    the refinement the default library applies at these sizes."""
+    import parity
+    from edge_cases import edge_qp
+
+    qp = edge_qp(case)
+    ref = parity.oracle_execution(qp, "refine", regularization=mpc.FixedRegularization(1e-8, -1e-8))
+    s = M.MPCSolver(to_device(qp, hip, True), hip, regularization=REG, driver="native")
+    assert type(s.qp.A).__name__ == "DeviceCSR"
+    r = s.solve()
+    s.close()
+    assert r["status"] == ref["status"] == M.SOLVE_SUCCEEDED and r["iter"] == ref["iter"], (case, r["iter"], ref["iter"])
+    for t, o in zip(r["trace"], ref["trace"]):
+        for key in ("alpha_p", "alpha_d", "inf_pr", "inf_du", "inf_compl", "mu"):
+            assert close(t[key], o[key], 1e-8), (case, t["k"], key, t[key], o[key])
+    assert close(r["objective"], ref["objective"], 1e-9)
+    assert np.max(np.abs(r["solution"] - ref["solution"])) <= 1e-7
