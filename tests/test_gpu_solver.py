@@ -490,7 +490,10 @@ def test_fused_iteration_is_bitwise_the_sequential_one_with_two_readbacks(hip):
              (Q.synthetic_qp(81, 150, 60, "lp"), dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=2), True),
              # round 5: the refinement steps are queued launches like the rest -- the fused form carries them too
              (Q.synthetic_qp(79, 140, 60, "lp"), dict(regularization=M.FixedRegularization(1e-8, -1e-8), refine_steps=1), True),
-             (Q.synthetic_qp(77, 200, 80), dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=3, refine_steps=1), True))
+             (Q.synthetic_qp(77, 200, 80), dict(regularization=M.FixedRegularization(1e-8, -1e-8), max_ncorr=3, refine_steps=1), True),
+             # the residual test of solve_system! switched on (src/linear_solver.jl:41): the device-side verdict compares too
+             (Q.synthetic_qp(83, 90, 30), dict(regularization=M.FixedRegularization(1e-8, -1e-8), check_residual=True,
+                                               tol_linear_solve=1e-6, max_ncorr=1), True))
     def run_waiting(qp, **kw):  # the fused form of round 4: nothing queued behind a read-back
         os.environ["MADQP_MPC_AHEAD"] = "0"
         try:
