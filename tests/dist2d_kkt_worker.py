@@ -91,6 +91,15 @@ def main():
     big.ucon[::3] *= 40.0
     rec["qp_scaled_rows"] = solve_case(be, grid2, big)
     grid2.close()
+    # the edges of the index lists (tests/edge_cases.py) on the grid: an empty upper list with one-sided rows, and every
+    # kind of variable and row at once (orders of a few dozen: one partial tile per rank that holds any)
+    from edge_cases import edge_qp
+
+    for name in ("lower_bounds_only", "mixed"):
+        eq = edge_qp(name)
+        grid3 = DistCholesky2D(be, eq.nvar, nb, (Pg, Qg), comm)
+        rec["edge_" + name] = solve_case(be, grid3, eq)
+        grid3.close()
     if comm is not None:
         assert comm.error is None, comm.error
     json.dump(rec, open(f"{out}.{rank}", "w"))

@@ -56,7 +56,7 @@ def check_kkt_records(recs):
 
     for rec in recs:
         assert rec["qp_900_350"]["pieces_equal"]
-        for name in ("qp_900_350", "qp_gondzio", "lp", "qp_eq", "qp_scaled_rows"):
+        for name in ("qp_900_350", "qp_gondzio", "lp", "qp_eq", "qp_scaled_rows", "edge_lower_bounds_only", "edge_mixed"):
             c = rec[name]
             fl = c["floor"] or dict(trace=[0.0] * len(c["ref_trace"]), dx=0.0, dy=0.0, obj=0.0)
             assert c["status"] == [1, 1], (name, c["status"])
@@ -70,7 +70,7 @@ def check_kkt_records(recs):
             assert c["dy"] <= max(1e-6, SENS_FACTOR * fl["dy"]), (name, c["dy"], fl["dy"])
             assert abs(c["obj"][0] - c["obj"][1]) <= max(1e-9, SENS_FACTOR * fl["obj"]) * max(1.0, abs(c["obj"][1])), name
             assert c["resid"] < 1e-7 or name == "qp_eq"  # (Theta = 1e8: the formulation's floor, test_kkt_system_conformance)
-    for name in ("qp_900_350", "qp_gondzio", "lp", "qp_eq", "qp_scaled_rows"):  # replicated state: bitwise equal ranks
+    for name in ("qp_900_350", "qp_gondzio", "lp", "qp_eq", "qp_scaled_rows", "edge_lower_bounds_only", "edge_mixed"):  # replicated state: bitwise equal ranks
         assert all(rec[name]["trace"] == recs[0][name]["trace"] and rec[name]["xsum"] == recs[0][name]["xsum"]
                    for rec in recs), name
 
