@@ -15,6 +15,9 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--count", type=int, default=100)
     p.add_argument("--seed0", type=int, default=1000)
+    p.add_argument("--nmin", type=int, default=1)
+    p.add_argument("--nmax", type=int, default=260, help="orders are drawn from [nmin, nmax): beyond 128 the mid-size "
+                   "factorisation with its sweep on U = L' runs, one more 128-block per 128 variables")
     p.add_argument("--mode", choices=("drivers", "sparse", "augmented"), default="drivers",
                    help="drivers: python / native / batched on dense data; sparse: CSR front end, condensed and (LPs) "
                         "normal equations, against the dense path's oracle; augmented: the K2 system (dense and CSR Jacobian) with "
@@ -30,7 +33,7 @@ def main():
     bad = 0
     for t in range(a.count):
         seed = a.seed0 + t
-        n = int(rng.integers(1, 260))
+        n = int(rng.integers(a.nmin, a.nmax))
         m = int(rng.integers(0, max(1, n)))
         lp = bool(rng.integers(0, 4) == 0)
         qp = Q.random_qp(seed, n, m, lp)
