@@ -11,7 +11,7 @@
 //     down to 128-column blocks jb:
 //       L_jj = chol(C_jj),  W_jj = L_jj^-1                   one workgroup, block resident in LDS
 //       L[jb+128:n, jb] = C[jb+128:n, jb] * W_jj'            gemm core, K = N = 128        (MFMA)
-// Matrices up to n = 10 240 take a right-looking schedule instead (chol_mid_step_kernel below): two launches per
+// Matrices up to n = 13 312 take a right-looking schedule instead (chol_mid_step_kernel below): two launches per
 // 128-column block, the diagonal block factored inside the launch that updates trailing tiles -- which tiles, with
 // which panels, a plan made once per handle decides (mid_plan.inc: updates are applied when there is room, two
 // panels at a time, no later than due).
@@ -1894,7 +1894,7 @@ static int32_t factor_range(madqp_chol* s, double* A, int64_t lda, int64_t j0, i
 // minus the visits it still needs -- while the step's budget of `rounds` x `cap` tiles lasts; a column whose slack is
 // used up is visited whatever the budget.  `rounds` is the smallest count for which no visit ever needs more than
 // MID_Q panels: 1 up to n = 5 120 on 256 CUs (every step then fits the shadow of the chain: 40 steps of ~47 us at
-// n = 5 000 instead of 8 of them at ~90 us), 2-4 up to 10 240.  The plan depends on (number of blocks, cap) only.
+// n = 5 000 instead of 8 of them at ~90 us), 2-4 up to 10 240, 5-6 up to 13 312.  The plan depends on (number of blocks, cap) only.
 // builds and uploads the plan of s (once); false: no plan (the caller runs the two-panel schedule)
 static bool mid_plan_build(madqp_chol* s, int nblk, int cap) {
     if (s->mid_plan_state) return s->mid_plan_state > 0;
@@ -1945,7 +1945,9 @@ static int32_t chol_factor_enqueue(madqp_chol* s, double* A, int64_t lda) {
     // (measured on bench.py, m = 0.4 n, ms per iteration against the left-looking schedule: 3.34 / 3.90 at n = 3 000,
     // 6.37 / 7.51 at 5 000, 13.7 / 15.1 at 8 000, 22.7 / 23.2 at 10 000, 34.4 / 33.0 at 12 000 -- every step rewrites
     // the whole trailing matrix, which the left-looking schedule does not)
-    static const int64_t mid_max = getenv("MADQP_CHOL_MID_MAX") ? atoll(getenv("MADQP_CHOL_MID_MAX")) : 10240;
+    // (round 5, with the backward sweep on U = L' behind this path -- ms per iteration, this path / left-looking: 19.1 / 21.0 at
+    // n = 10 000, 23.7 / 25.4 at 11 000, 29.2 / 30.5 at 12 000, 35.5 / 36.4 at 13 000, 42.8 / 42.6 at 14 000, 60.8 / 58.1 at 16 000)
+    static const int64_t mid_max = getenv("MADQP_CHOL_MID_MAX") ? atoll(getenv("MADQP_CHOL_MID_MAX")) : 13312;
     const int64_t npad_m = (n + NB - 1) / NB * NB;
     if (n <= mid_max && n > NB && s->npos == n && lda >= npad_m && lda % 2 == 0 && (((uintptr_t)A) & 15) == 0) {
         const int32_t nblk = (int32_t)(npad_m / NB);

@@ -112,7 +112,7 @@ def _spd(n, rng, cond=1e3):
                          + [(n, True) for n in [129, 255, 300, 1024, 1100, 2300, 4100]])
 def test_cholesky_factor_and_solve(hip, n, padded):
     """padded: the leading dimension covers the order rounded up to 128, as the KKT objects allocate K -- the
-    layout that takes the right-looking mid-size schedule (chol.hip, chol_mid_step_kernel) up to n = 10 240."""
+    layout that takes the right-looking mid-size schedule (chol.hip, chol_mid_step_kernel) up to n = 13 312."""
     rng = np.random.default_rng(n)
     K = _spd(n, rng)
     K = 0.5 * (K + K.T)
@@ -379,7 +379,7 @@ def test_sweeps_leave_the_residual_of_substitution():
 
 
 def test_mid_size_schedules_factor_the_same_matrix():
-    """chol_factor_enqueue's mid-size path (n <= 10 240) has three schedules of the trailing update: planned visits
+    """chol_factor_enqueue's mid-size path (n <= 13 312) has three schedules of the trailing update: planned visits
     (default, mid_plan.inc), two panels every second step (MADQP_CHOL_MID_LAZY=0) and every panel at once
     (+ MADQP_CHOL_MID_TWO=0; + MADQP_CHOL_MID_DSYRK=0: the diagonal tile by the GEMM path).  All must give LAPACK's
     factor up to rounding -- orders with a ragged last block and a single trailing block -- and, since every tile
@@ -399,7 +399,7 @@ def test_mid_size_schedules_factor_the_same_matrix():
         import madqp_jl_amd as M
         be = M.HipBackend(0)
         out = {}
-        for n in (129, 257, 1000, 2500, 5001):
+        for n in (129, 257, 1000, 2500, 5001, 12900):
             rng = np.random.default_rng(n)
             G = torch.as_tensor(rng.standard_normal((n, n + 8)), device=be.device)
             K = G @ G.T + n * torch.eye(n, dtype=torch.float64, device=be.device)
